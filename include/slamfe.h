@@ -1,0 +1,203 @@
+/* slamfe.h -- C ABI of the MI355X feature front-end (libslamfe.so).
+ *
+ * The library replaces the four OpenCV call sites of the reference's tracking
+ * thread and nothing else:
+ *
+ *   Init.cc:64-66   cv::FastFeatureDetector::create / cv::ORB::create /
+ *                   new cv::BFMatcher            -> slamfe_create
+ *   Init.cc:75-78   cvtColor + detect + compute  -> slamfe_extract
+ *   Init.cc:131     knnMatch(desc1, desc2, 2)    -> slamfe_match_knn2
+ *   Init.cc:144-153 Lowe ratio loop              -> slamfe_match2.ratio_pass
+ *   Init.cc:229-259 search by projection         -> slamfe_search_by_projection
+ *   Init.cc:296     Point(..., desc2.row(idx))   -> slamfe_map_put
+ *
+ * Conventions
+ *   - Plain C, no exceptions: every call returns SLAMFE_OK (0) or a negative
+ *     SLAMFE_E_* code; slamfe_last_error() gives the text for the last failure
+ *     on that context.  (The reference lets cv::Exception terminate the
+ *     process; a host that wants that behaviour aborts on a non-zero return.)
+ *   - Outputs are caller-allocated; the library copies (it never aliases a
+ *     caller buffer after the call returns, unlike the shared cv::Mat buffers
+ *     of Init.cc:296 / Init.cc:323).
+ *   - A context owns one GPU, one HIP stream and all device buffers.  It is not
+ *     re-entrant: use it from one host thread at a time (the reference calls
+ *     the front-end only from the processFrames thread, Init.cc:83).
+ *   - Pointers named d_* are device pointers on the context's GPU; all others
+ *     are host pointers.
+ */
+#ifndef SLAMFE_H
+#define SLAMFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMFE_OK 0
+#define SLAMFE_E_INVALID (-1)  /* bad argument */
+#define SLAMFE_E_CAPACITY (-2) /* caller or context capacity too small; see call */
+#define SLAMFE_E_DEVICE (-3)   /* HIP runtime error */
+#define SLAMFE_E_NOMEM (-4)
+#define SLAMFE_E_HANDLE (-5)   /* frame handle expired or unknown */
+
+/* Operating mode of slamfe_extract.
+ * SLAMFE_MODE_ORB       full ORB: image pyramid, per-level FAST + retain-best
+ *                       quota, intensity-centroid orientation, blur, rBRIEF
+ *                       (what cv::ORB::detectAndCompute does).
+ * SLAMFE_MODE_PROVIDED  what the reference literally runs (Init.cc:76 then
+ *                       Init.cc:78): FAST on the full-resolution image, then
+ *                       ORB::compute on those keypoints -- one level, no quota,
+ *                       angle fixed at -1 degree, 31-px border filter. */
+#define SLAMFE_MODE_ORB 0
+#define SLAMFE_MODE_PROVIDED 1
+
+/* Layout-identical to cv::KeyPoint (28 bytes).  Consumers in the reference
+ * read only pt (Init.cc:150-151, 241, 280-283; optimizer.cc:97-98). */
+typedef struct slamfe_keypoint {
+    float x, y;     /* pt, in full-resolution pixels */
+    float size;     /* 7 (FAST) or 31 * level scale (ORB) */
+    float angle;    /* degrees in [0,360), or -1 */
+    float response; /* FAST score */
+    int32_t octave; /* pyramid level */
+    int32_t class_id; /* -1 */
+} slamfe_keypoint;
+
+/* One row of a k=2 match result: what knnMatch (Init.cc:131) returns for one
+ * query plus the ratio test of Init.cc:146-147.  Order rule: (distance, train
+ * index) ascending.  idx = -1 where fewer than 1 / 2 train rows exist. */
+typedef struct slamfe_match2 {
+    int32_t idx0, idx1;
+    uint16_t d0, d1;     /* Hamming distances, 0..256 */
+    uint8_t ratio_pass;  /* nfound == 2 && (float)d0 < ratio * (float)d1 */
+    uint8_t nfound;      /* min(2, train rows) */
+    uint8_t reserved[2];
+} slamfe_match2;
+
+typedef struct slamfe_params {
+    int32_t struct_size;     /* sizeof(slamfe_params), set by slamfe_default_params */
+    int32_t mode;            /* SLAMFE_MODE_* */
+    int32_t fast_threshold;  /* thold: 30 in main.cc:11 */
+    int32_t nfeatures;       /* 10000 in main.cc:11 (only used in SLAMFE_MODE_ORB) */
+    float scale_factor;      /* 1.2f, Init.cc:65 */
+    int32_t nlevels;         /* 8, Init.cc:65 */
+    int32_t edge_threshold;  /* 31, Init.cc:65 */
+    int32_t patch_size;      /* 31, Init.cc:65 (only 31 is implemented) */
+    float ratio;             /* 0.75f, Init.cc:146 */
+    int32_t device_id;       /* HIP device ordinal */
+    int32_t max_width;       /* largest frame the context accepts (<= 4096) */
+    int32_t max_height;
+    int32_t max_batch;       /* frames per slamfe_extract_batch / _resident call */
+    int32_t max_keypoints;   /* per-frame keypoint capacity on the device */
+    int32_t frame_slots;     /* device-resident frame results kept (ring) */
+    int32_t map_capacity;    /* rows of the device-resident map descriptor table */
+    void* stream;            /* hipStream_t to run on, or NULL to create one */
+} slamfe_params;
+
+typedef struct slamfe_ctx slamfe_ctx;
+
+/* Fill *p with the reference's constants (Init.cc:64-66, main.cc:11). */
+int slamfe_default_params(slamfe_params* p);
+
+/* Replaces the object construction of Init.cc:64-66. */
+int slamfe_create(const slamfe_params* p, slamfe_ctx** out);
+void slamfe_destroy(slamfe_ctx* ctx);
+const char* slamfe_last_error(const slamfe_ctx* ctx);
+
+/* Replaces Init::extractKeyPoints (Init.cc:74-79).
+ * img: h rows of `stride` bytes, 1 channel (gray) or 3 (BGR, converted as
+ * cv::COLOR_BGR2GRAY does).  kps/desc: caller buffers for `cap` keypoints and
+ * cap*32 descriptor bytes (row-major, as a continuous CV_8U Mat).
+ * Keypoint order: (level, y, x) ascending; in SLAMFE_MODE_PROVIDED that is
+ * FAST's own row-major order.  *frame_handle names the device-resident copy.
+ * Returns SLAMFE_E_CAPACITY with *n_out = needed count if cap (or the
+ * context's max_keypoints) is too small. */
+int slamfe_extract(slamfe_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                   slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                   uint64_t* frame_handle);
+
+/* The same for n <= max_batch frames of one size; frame i uses imgs[i],
+ * kps + i*cap, desc + i*cap*32, n_out[i], frame_handles[i].  kps and desc may
+ * be NULL to leave the results on the device only. */
+int slamfe_extract_batch(slamfe_ctx* ctx, const uint8_t* const* imgs, int n, int w, int h,
+                         int stride, int channels, slamfe_keypoint* kps, uint8_t* desc, int cap,
+                         int* n_out, uint64_t* frame_handles);
+
+/* Extraction from frames that already sit in device memory (frame i at
+ * d_imgs + i*frame_stride_bytes).  Asynchronous on the context's stream; no
+ * host synchronisation.  Results stay device-resident under the handles. */
+int slamfe_extract_resident(slamfe_ctx* ctx, const void* d_imgs, int n, int w, int h, int stride,
+                            size_t frame_stride_bytes, int channels, uint64_t* frame_handles);
+
+/* Copy a device-resident frame result to the host (synchronises). */
+int slamfe_frame_download(slamfe_ctx* ctx, uint64_t frame_handle, slamfe_keypoint* kps,
+                          uint8_t* desc, int cap, int* n_out);
+
+/* Replaces matcher->knnMatch(desc1, desc2, matches, 2) + the ratio loop
+ * (Init.cc:131-153).  query = desc1 (previous frame), train = desc2.
+ * out[i] for i < nq. */
+int slamfe_match_knn2(slamfe_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                      slamfe_match2* out);
+
+/* The same on two device-resident frames; out may be NULL (result stays on the
+ * device, readable with slamfe_match_download).  *nq_out = rows written. */
+int slamfe_match_frames(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
+                        slamfe_match2* out, int cap, int* nq_out);
+
+/* Asynchronous form: both frames device-resident, result written to
+ * d_out[0..max_keypoints) (device memory), row counts read on the device. */
+int slamfe_match_resident(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
+                          slamfe_match2* d_out);
+
+/* Sharded brute-force matching (relocalisation against a map split over
+ * several GPUs).  d_query: nq x 32 B, d_train: this shard's nt x 32 B whose
+ * first row has global index train_base.  Writes, per query, the shard's two
+ * best candidates as keys (distance << 32 | global index), ascending;
+ * missing candidates are UINT64_MAX.  Integer min on keys is the (distance,
+ * index) order of Init.cc:131, so merging shards reproduces the single-GPU
+ * result exactly.  Asynchronous. */
+int slamfe_match_shard_keys(slamfe_ctx* ctx, const void* d_query, int nq, const void* d_train,
+                            int nt, int64_t train_base, uint64_t* d_keys);
+
+/* Merge nshards key sets (laid out [shard][nq][2], e.g. the output of an
+ * all-gather) into match rows + ratio flag.  Asynchronous. */
+int slamfe_merge_shard_keys(slamfe_ctx* ctx, const uint64_t* d_keys_all, int nshards, int nq,
+                            slamfe_match2* d_out);
+
+/* Device mirror of Point::desc (keyframe.h:32): row point_ids[i] of the map
+ * descriptor table := desc32[i*32 .. +32).  Called where the reference creates
+ * a Point from descriptors2.row(idx) (Init.cc:296).  Ids are dense
+ * (m.getPointsSize()), < map_capacity. */
+int slamfe_map_put(slamfe_ctx* ctx, const int32_t* point_ids, const uint8_t* desc32, int n);
+
+/* Replaces the inner search of Init.cc:229-259.
+ * frame: handle of the current frame (descriptors2 / keypoints2).
+ * kp_idx[i]: goodMatches[i].trainIdx of the i-th RANSAC inlier, in loop order.
+ * uv / point_ids: rPoints / the map ids behind rPointsIdx (R visible points,
+ * ascending, Init.cc:203-218).  For inlier i the best remaining visible point
+ * is the one with Hamming distance <= max_hamming and pixel distance <= radius
+ * that has the smallest Hamming distance (lowest position on ties); it is then
+ * removed from the candidates of later inliers (Init.cc:255-256).
+ * matched_point_id[i] = that point's id, or -1 (the caller then triangulates,
+ * Init.cc:260). */
+int slamfe_search_by_projection(slamfe_ctx* ctx, uint64_t frame, const int32_t* kp_idx, int n_inl,
+                                const float* uv, const int32_t* point_ids, int R, float radius,
+                                int max_hamming, int32_t* matched_point_id);
+
+/* Wait for everything queued on the context's stream. */
+int slamfe_sync(slamfe_ctx* ctx);
+
+/* Device pointers of a resident frame (valid until the slot is recycled after
+ * frame_slots further frames): keypoints, 32-byte descriptor rows, and the
+ * device-side count. */
+int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamfe_keypoint** d_kps,
+                             const uint8_t** d_desc, const int32_t** d_count);
+
+/* Library version, for the loader's sanity check. */
+int slamfe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMFE_H */

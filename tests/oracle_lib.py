@@ -1,0 +1,193 @@
+"""ctypes binding of the CPU checker (oracle/libslamfe_oracle.so).
+
+Test infrastructure: only tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py load this library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from slam_amd import abi
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libslamfe_oracle.so")
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+
+
+def _p(a, t=u8p):
+    return a.ctypes.data_as(t)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def load():
+    if not os.path.exists(_SO):
+        build()
+    return C.CDLL(_SO)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+        _lib.orc_fast_atan2.restype = C.c_float
+        _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.orc_ic_angle.restype = C.c_float
+    return _lib
+
+
+class Corner(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("score", C.c_int)]
+
+
+CORNER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+
+
+def bgr2gray(bgr):
+    h, w, _ = bgr.shape
+    bgr = np.ascontiguousarray(bgr)
+    out = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray(_p(bgr), w, h, w * 3, _p(out), w)
+    return out
+
+
+def fast_score_map(img, thr):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_fast_score_map(_p(img), w, h, w, thr, _p(out), w)
+    return out
+
+
+def fast9(img, thr, nonmax=True):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    cap = w * h // 4 + 16 if nonmax else w * h
+    out = np.zeros(cap, CORNER_DTYPE)
+    n = lib().orc_fast9(_p(img), w, h, w, thr, int(nonmax), out.ctypes.data_as(C.c_void_p), cap)
+    return out[:n]
+
+
+def level_geometry(w, h, nlevels=8, scale_factor=1.2):
+    lw = np.zeros(nlevels, np.int32)
+    lh = np.zeros(nlevels, np.int32)
+    ls = np.zeros(nlevels, np.float32)
+    lib().orc_level_geometry(w, h, nlevels, C.c_float(scale_factor), _p(lw, i32p), _p(lh, i32p),
+                             _p(ls, f32p))
+    return lw, lh, ls
+
+
+def level_quotas(nfeatures, nlevels=8, scale_factor=1.2):
+    q = np.zeros(nlevels, np.int32)
+    lib().orc_level_quotas(nfeatures, nlevels, C.c_float(scale_factor), _p(q, i32p))
+    return q
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src)
+    sh, sw = src.shape
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear_exact(_p(src), sw, sh, sw, _p(out), dw, dh, dw)
+    return out
+
+
+def build_pyramid(gray, nlevels=8, scale_factor=1.2):
+    gray = np.ascontiguousarray(gray)
+    h, w = gray.shape
+    lw, lh, _ = level_geometry(w, h, nlevels, scale_factor)
+    levels = [np.empty((lh[l], lw[l]), np.uint8) for l in range(nlevels)]
+    ptrs = (u8p * nlevels)(*[_p(a) for a in levels])
+    lib().orc_build_pyramid(_p(gray), w, h, w, nlevels, C.c_float(scale_factor), ptrs)
+    return levels
+
+
+def blur7(img):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_gaussian_blur7(_p(img), w, h, w, _p(out), w)
+    return out
+
+
+def ic_moments(img, cx, cy):
+    img = np.ascontiguousarray(img)
+    m10 = C.c_int()
+    m01 = C.c_int()
+    lib().orc_ic_moments(_p(img), img.shape[1], cx, cy, C.byref(m10), C.byref(m01))
+    return m10.value, m01.value
+
+
+def ic_angle(img, cx, cy):
+    img = np.ascontiguousarray(img)
+    return float(lib().orc_ic_angle(_p(img), img.shape[1], cx, cy))
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def sincos_deg(angle, trig_mode=0):
+    s = C.c_float()
+    c = C.c_float()
+    lib().orc_sincos_deg(C.c_float(angle), trig_mode, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def brief256(blurred, cx, cy, angle, trig_mode=0):
+    blurred = np.ascontiguousarray(blurred)
+    out = np.zeros(32, np.uint8)
+    lib().orc_brief256(_p(blurred), blurred.shape[1], cx, cy, C.c_float(angle), trig_mode, _p(out))
+    return out
+
+
+def extract(params, img, trig_mode=0, cap=None):
+    img = np.ascontiguousarray(img)
+    if img.ndim == 3:
+        h, w, ch = img.shape
+    else:
+        (h, w), ch = img.shape, 1
+    if cap is None:
+        cap = w * h // 4 + 16 if params.mode == abi.MODE_PROVIDED else 4 * params.nfeatures + 4096
+    kps = np.zeros(cap, abi.KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = lib().orc_extract(C.byref(params), _p(img), w, h, w * ch, ch, trig_mode,
+                          kps.ctypes.data_as(C.c_void_p), _p(desc), cap)
+    assert n <= cap, (n, cap)
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def match_knn2(query, train, ratio=0.75):
+    query = np.ascontiguousarray(query)
+    train = np.ascontiguousarray(train)
+    nq, nt = len(query), len(train)
+    out = np.zeros(max(nq, 1), abi.MATCH2_DTYPE)
+    lib().orc_match_knn2(_p(query), nq, _p(train), nt, C.c_float(ratio),
+                         out.ctypes.data_as(C.c_void_p))
+    return out[:nq]
+
+
+def search_by_projection(kp_xy, frame_desc, kp_idx, uv, point_desc, point_ids, radius=32.0,
+                         max_hamming=128):
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+    frame_desc = np.ascontiguousarray(frame_desc)
+    kp_idx = np.ascontiguousarray(kp_idx, np.int32)
+    uv = np.ascontiguousarray(uv, np.float32)
+    point_desc = np.ascontiguousarray(point_desc)
+    point_ids = np.ascontiguousarray(point_ids, np.int32)
+    out = np.full(max(len(kp_idx), 1), -2, np.int32)
+    lib().orc_search_by_projection(_p(kp_xy, f32p), _p(frame_desc), _p(kp_idx, i32p), len(kp_idx),
+                                   _p(uv, f32p), _p(point_desc), _p(point_ids, i32p), len(uv),
+                                   C.c_float(radius), max_hamming, _p(out, i32p))
+    return out[:len(kp_idx)]

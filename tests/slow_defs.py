@@ -1,0 +1,188 @@
+"""Independent slow definitions (numpy / pure Python) of each stage.
+
+These restate the *definitions* -- not the optimised algorithms -- so that the C
+checker in oracle/ can be cross-checked by something that shares no code with
+it.  Used on small inputs only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3),
+        (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+UMAX = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+GAUSS = np.array([18, 34, 49, 55, 49, 34, 18], dtype=np.int64)
+
+
+def ring_stack(img):
+    """[16, h-6, w-6] ring pixel values for every interior pixel."""
+    h, w = img.shape
+    im = img.astype(np.int64)
+    return np.stack([im[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in RING])
+
+
+def is_corner_at(img, t):
+    """Segment test at threshold t for all interior pixels: 9 contiguous ring
+    pixels all > v+t or all < v-t."""
+    h, w = img.shape
+    v = img.astype(np.int64)[3:h - 3, 3:w - 3]
+    r = ring_stack(img)
+    out = np.zeros(v.shape, bool)
+    for mask in (r > v + t, r < v - t):
+        m2 = np.concatenate([mask, mask[:8]])
+        for s in range(16):
+            out |= m2[s:s + 9].all(axis=0)
+    return out
+
+
+def fast_score_map(img, thr):
+    """score = the largest threshold at which the pixel still passes the
+    segment test (0 where it fails at thr)."""
+    h, w = img.shape
+    score = np.zeros((h, w), np.int64)
+    if h < 7 or w < 7:
+        return score, np.zeros((h, w), bool)
+    alive = is_corner_at(img, thr)
+    inner = np.where(alive, thr, 0)
+    t = thr + 1
+    while alive.any() and t <= 255:
+        alive &= is_corner_at(img, t)
+        inner[alive] = t
+        t += 1
+    score[3:h - 3, 3:w - 3] = inner
+    return score, np.pad(is_corner_at(img, thr), 3)
+
+
+def fast_nms(img, thr):
+    """Row-major list of (x, y, score) after strict 3x3 non-max suppression."""
+    score, corner = fast_score_map(img, thr)
+    h, w = img.shape
+    p = np.pad(score, 1)
+    keep = corner.copy()
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            if dx == 0 and dy == 0:
+                continue
+            keep &= score > p[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+    ys, xs = np.nonzero(keep)
+    return np.stack([xs, ys, score[ys, xs]], axis=1)
+
+
+def resize_linear_exact(src, dw, dh):
+    sh, sw = src.shape
+
+    def taps(ssize, dsize):
+        ofs, c1 = [], []
+        scale = 1.0 / (float(dsize) / float(ssize))
+        for d in range(dsize):
+            f = scale * (d + 0.5) - 0.5
+            i0 = int(np.floor(f))
+            if i0 >= 0 and ssize > 1:
+                if i0 < ssize - 1:
+                    ofs.append(i0)
+                    c1.append(int(np.rint((f - i0) * 256.0)))
+                else:
+                    ofs.append(ssize - 1)
+                    c1.append(0)
+            else:
+                ofs.append(0)
+                c1.append(0)
+        return np.array(ofs), np.array(c1, dtype=np.int64)
+
+    xo, xc = taps(sw, dw)
+    yo, yc = taps(sh, dh)
+    s = src.astype(np.int64)
+    xo1 = np.minimum(xo + 1, sw - 1)
+    yo1 = np.minimum(yo + 1, sh - 1)
+    hrow = s[:, xo] * (256 - xc) + s[:, xo1] * xc
+    out = (hrow[yo] * (256 - yc)[:, None] + hrow[yo1] * yc[:, None] + (1 << 15)) >> 16
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def blur7(img):
+    p = np.pad(img.astype(np.int64), 3, mode="reflect")
+    h, w = img.shape
+    rows = sum(GAUSS[k] * p[:, k:k + w] for k in range(7))
+    out = sum(GAUSS[k] * rows[k:k + h] for k in range(7))
+    return np.clip((out + (1 << 15)) >> 16, 0, 255).astype(np.uint8)
+
+
+def ic_moments(img, cx, cy):
+    m10 = m01 = 0
+    for v in range(-15, 16):
+        d = UMAX[abs(v)]
+        for u in range(-d, d + 1):
+            val = int(img[cy + v, cx + u])
+            m10 += u * val
+            m01 += v * val
+    return m10, m01
+
+
+def hamming_matrix(q, t):
+    qb = np.unpackbits(q, axis=1).astype(np.int32)
+    tb = np.unpackbits(t, axis=1).astype(np.int32)
+    return qb @ (1 - tb).T + (1 - qb) @ tb.T
+
+
+def knn2(q, t, ratio=0.75):
+    """(idx0, idx1, d0, d1, pass) by stable argsort: order (distance, index)."""
+    d = hamming_matrix(q, t)
+    order = np.argsort(d, axis=1, kind="stable")
+    out = []
+    for i in range(len(q)):
+        idx = order[i, :2]
+        ds = d[i, idx]
+        i0 = int(idx[0]) if len(idx) > 0 else -1
+        i1 = int(idx[1]) if len(idx) > 1 else -1
+        d0 = int(ds[0]) if len(idx) > 0 else 0
+        d1 = int(ds[1]) if len(idx) > 1 else 0
+        ok = len(idx) == 2 and np.float32(d0) < np.float32(ratio) * np.float32(d1)
+        out.append((i0, i1, d0, d1, int(ok)))
+    return out
+
+
+def brief256(blurred, cx, cy, angle_deg, pattern):
+    """pattern: [256, 4] int.  float32 arithmetic with separate roundings."""
+    theta = np.float32(angle_deg) * np.float32(np.pi / 180.0)
+    a = np.float32(np.cos(np.float64(theta)))
+    b = np.float32(np.sin(np.float64(theta)))
+    pat = pattern.astype(np.float32)
+
+    def sample(px, py):
+        x = (px * a).astype(np.float32) - (py * b).astype(np.float32)
+        y = (px * b).astype(np.float32) + (py * a).astype(np.float32)
+        ix = np.rint(x.astype(np.float32)).astype(np.int64)
+        iy = np.rint(y.astype(np.float32)).astype(np.int64)
+        return blurred[cy + iy, cx + ix].astype(np.int64)
+
+    t0 = sample(pat[:, 0], pat[:, 1])
+    t1 = sample(pat[:, 2], pat[:, 3])
+    bits = (t0 < t1).astype(np.uint8)
+    return np.packbits(bits, bitorder="little")
+
+
+def search_by_projection(kp_xy, frame_desc, kp_idx, uv, point_desc, point_ids, radius=32.0,
+                         max_hamming=128):
+    """Literal restatement of the nested loop with list erase."""
+    rpoints = [tuple(p) for p in uv]
+    ridx = list(range(len(uv)))
+    out = []
+    for idx in kp_idx:
+        best = None
+        mind = float("inf")
+        for j, k in enumerate(ridx):
+            dist = int(np.unpackbits(point_desc[k] ^ frame_desc[idx]).sum())
+            dx = np.float32(rpoints[j][0]) - np.float32(kp_xy[idx][0])
+            dy = np.float32(rpoints[j][1]) - np.float32(kp_xy[idx][1])
+            e = np.float32(np.sqrt(np.float64(dx) ** 2 + np.float64(dy) ** 2))
+            if dist <= max_hamming and e <= radius:
+                if dist < mind:
+                    mind = dist
+                    best = j
+        if best is None:
+            out.append(-1)
+        else:
+            out.append(int(point_ids[ridx[best]]))
+            del rpoints[best]
+            del ridx[best]
+    return np.array(out, dtype=np.int32)

@@ -1,0 +1,422 @@
+"""The CPU checker against analytical known-answers and against independent
+slow definitions (tests/slow_defs.py).  No GPU needed.
+
+The reference ships no tests or vectors for this path, so these are the pins
+the checker has; see the header of oracle/slamfe_oracle.h.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import slow_defs as S
+from slam_amd import abi, synth
+from slam_amd.tables import PATTERN, PATTERN_CRC32
+
+
+def small_textured(w=96, h=80, seed=11):
+    return synth.textured_canvas(w, h, seed)
+
+
+# ---------------------------------------------------------------- tables
+def test_pattern_crc_and_shape():
+    assert PATTERN.shape == (256, 4)
+    assert zlib.crc32(PATTERN.astype(np.int8).tobytes()) == PATTERN_CRC32 == 0xD1A39030
+    assert PATTERN.min() == -13 and PATTERN.max() <= 13
+    assert len({tuple(r) for r in PATTERN}) == 256
+    r = np.sqrt((PATTERN[:, 0:2] ** 2).sum(1).max()), np.sqrt((PATTERN[:, 2:4] ** 2).sum(1).max())
+    assert max(r) < 19  # rotated samples stay inside the 31-px border
+
+
+def test_umax_is_the_749_pixel_disc():
+    assert sum(2 * u + 1 for u in S.UMAX) * 2 - (2 * S.UMAX[0] + 1) == 749
+
+
+# ------------------------------------------------------------------ gray
+def test_gray_known_answers():
+    bgr = np.zeros((2, 3, 3), np.uint8)
+    bgr[0, 0] = (255, 255, 255)
+    bgr[0, 1] = (255, 0, 0)
+    bgr[0, 2] = (0, 255, 0)
+    bgr[1, 0] = (0, 0, 255)
+    bgr[1, 1] = (10, 20, 30)
+    g = O.bgr2gray(bgr)
+    assert g[0, 0] == 255 and g[1, 2] == 0
+    assert g[0, 1] == (255 * 1868 + 8192) >> 14
+    assert g[0, 2] == (255 * 9617 + 8192) >> 14
+    assert g[1, 0] == (255 * 4899 + 8192) >> 14
+    assert g[1, 1] == (10 * 1868 + 20 * 9617 + 30 * 4899 + 8192) >> 14
+
+
+def test_gray_random_matches_formula():
+    rng = synth.rand_below(5, 1, np.arange(40 * 30 * 3), 256).astype(np.uint8).reshape(30, 40, 3)
+    want = (rng[..., 0].astype(np.int64) * 1868 + rng[..., 1].astype(np.int64) * 9617 +
+            rng[..., 2].astype(np.int64) * 4899 + 8192) >> 14
+    assert np.array_equal(O.bgr2gray(rng), want.astype(np.uint8))
+
+
+# ------------------------------------------------------------------ FAST
+def test_fast_flat_and_step_edge_have_no_corners():
+    flat = np.full((32, 32), 77, np.uint8)
+    assert len(O.fast9(flat, 20)) == 0
+    step = np.zeros((32, 32), np.uint8)
+    step[:, 16:] = 200
+    assert len(O.fast9(step, 20)) == 0  # an edge gives at most 7-8 contiguous ring pixels
+
+
+def test_fast_isolated_bright_pixel():
+    img = np.full((32, 32), 50, np.uint8)
+    img[16, 16] = 150  # delta 100 > thr: the whole ring is darker
+    c = O.fast9(img, 20)
+    assert len(c) == 1 and (c[0]["x"], c[0]["y"], c[0]["score"]) == (16, 16, 99)
+    sm = O.fast_score_map(img, 20)
+    assert sm[16, 16] == 99 and sm.sum() == 99  # ring neighbours are not corners
+
+
+def test_fast_dark_square_corner():
+    img = np.full((40, 40), 200, np.uint8)
+    img[10:30, 10:30] = 20
+    c = O.fast9(img, 20, nonmax=False)  # scores tie on synthetic squares, so skip NMS
+    got = {(int(k["x"]), int(k["y"])) for k in c}
+    # each corner of the square yields corner pixels near it
+    for cx, cy in ((10, 10), (29, 10), (10, 29), (29, 29)):
+        assert any(abs(x - cx) <= 2 and abs(y - cy) <= 2 for x, y in got)
+
+
+@pytest.mark.parametrize("thr", [0, 7, 20, 30])
+def test_fast_score_map_is_largest_passing_threshold(thr):
+    img = small_textured()
+    want, _ = S.fast_score_map(img, thr)
+    assert np.array_equal(O.fast_score_map(img, thr).astype(np.int64), want)
+
+
+@pytest.mark.parametrize("thr", [1, 20, 30])
+def test_fast_nms_row_major(thr):
+    img = small_textured(120, 72, 12)
+    want = S.fast_nms(img, thr)
+    got = O.fast9(img, thr)
+    assert len(got) > 10
+    assert np.array_equal(np.stack([got["x"], got["y"], got["score"]], 1), want)
+    keys = got["y"].astype(np.int64) * 1000 + got["x"]
+    assert np.all(np.diff(keys) > 0)
+
+
+def test_fast_ties_are_both_suppressed():
+    # two adjacent pixels with equal score: strict '>' drops both
+    img = np.full((32, 32), 50, np.uint8)
+    img[16, 15] = 150
+    img[16, 16] = 150
+    sm = O.fast_score_map(img, 20)
+    c = O.fast9(img, 20)
+    if sm[16, 15] == sm[16, 16] and sm[16, 15] > 0:
+        assert not any(k["y"] == 16 and k["x"] in (15, 16) for k in c)
+
+
+def test_fast_tiny_images():
+    assert len(O.fast9(np.zeros((6, 40), np.uint8), 20)) == 0
+    assert len(O.fast9(np.zeros((40, 6), np.uint8), 20)) == 0
+
+
+# -------------------------------------------------------------- geometry
+def test_level_geometry_and_quotas_known_values():
+    lw, lh, ls = O.level_geometry(640, 480)
+    assert list(lw) == [640, 533, 444, 370, 309, 257, 214, 179]
+    assert list(lh) == [480, 400, 333, 278, 231, 193, 161, 134]
+    assert list(O.level_quotas(2000)) == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert list(O.level_quotas(3000)) == [652, 543, 452, 377, 314, 262, 218, 182]
+    assert list(O.level_quotas(5000)) == [1086, 905, 754, 628, 524, 436, 364, 303]
+    assert list(O.level_quotas(10000)) == [2172, 1810, 1508, 1257, 1047, 873, 727, 606]
+    lw, lh, _ = O.level_geometry(1241, 376)
+    assert (lw[0], lh[0], lw[7], lh[7]) == (1241, 376, 346, 105)
+    assert int((O.level_geometry(1920, 1080)[0].astype(np.int64) *
+                O.level_geometry(1920, 1080)[1]).sum()) == 6419321
+    assert int((O.level_geometry(3840, 2160)[0].astype(np.int64) *
+                O.level_geometry(3840, 2160)[1]).sum()) == 25677702
+
+
+def test_descriptor_centre_round_trip_is_identity():
+    # cvRound((x * scale) * (1/scale)) == x for every level and coordinate
+    _, _, ls = O.level_geometry(4096, 4096)
+    x = np.arange(4096, dtype=np.float32)
+    for s in ls:
+        s = np.float32(s)
+        inv = np.float32(1.0) / s
+        assert np.array_equal(np.rint((x * s) * inv).astype(np.int64), np.arange(4096))
+
+
+# ---------------------------------------------------------------- resize
+def test_resize_constant_and_identity():
+    c = np.full((50, 70), 93, np.uint8)
+    assert np.all(O.resize(c, 58, 42) == 93)
+    img = small_textured()
+    assert np.array_equal(O.resize(img, img.shape[1], img.shape[0]), img)
+
+
+@pytest.mark.parametrize("shape,dst", [((80, 96), (80, 67)), ((67, 80), (67, 56)),
+                                       ((480, 640), (533, 400)), ((31, 45), (37, 26))])
+def test_resize_matches_slow_definition(shape, dst):
+    img = synth.textured_canvas(shape[1], shape[0], 13)
+    dw, dh = dst
+    assert np.array_equal(O.resize(img, dw, dh), S.resize_linear_exact(img, dw, dh))
+
+
+def test_resize_exact_half_is_2x2_average():
+    img = small_textured(64, 48, 14)
+    got = O.resize(img, 32, 24)
+    s = img.astype(np.int64)
+    # taps are exactly 0.5/0.5 -> (a+b+c+d)*128*128 + 2^15 >> 16
+    want = ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2]) * 16384 + 32768) >> 16
+    assert np.array_equal(got, want.astype(np.uint8))
+
+
+def test_pyramid_is_cumulative():
+    img = synth.textured_canvas(200, 150, 15)
+    lv = O.build_pyramid(img)
+    lw, lh, _ = O.level_geometry(200, 150)
+    assert np.array_equal(lv[0], img)
+    for l in range(1, 8):
+        assert np.array_equal(lv[l], S.resize_linear_exact(lv[l - 1], int(lw[l]), int(lh[l])))
+
+
+# ------------------------------------------------------------------ blur
+def test_blur_constant_and_saturation():
+    for c in (0, 1, 100, 254, 255):
+        img = np.full((20, 24), c, np.uint8)
+        want = min(255, (c * 257 * 257 + 32768) >> 16)
+        assert np.all(O.blur7(img) == want)
+
+
+def test_blur_matches_slow_definition_including_borders():
+    for shape, seed in (((40, 56), 16), ((9, 11), 17), ((120, 90), 18)):
+        img = synth.textured_canvas(shape[1], shape[0], seed)
+        assert np.array_equal(O.blur7(img), S.blur7(img))
+
+
+# ----------------------------------------------------------- orientation
+def test_fast_atan2_known_answers_and_accuracy():
+    assert abs(O.fast_atan2(0, 1) - 0) < 1e-4
+    assert abs(O.fast_atan2(1, 0) - 90) < 1e-4
+    assert abs(O.fast_atan2(0, -1) - 180) < 1e-4
+    assert abs(O.fast_atan2(-1, 0) - 270) < 1e-4
+    worst = 0.0
+    for i in range(2000):
+        a = 2 * np.pi * i / 2000
+        y, x = np.float32(1000 * np.sin(a)), np.float32(1000 * np.cos(a))
+        true = np.degrees(np.arctan2(float(y), float(x))) % 360
+        err = abs((O.fast_atan2(y, x) - true + 180) % 360 - 180)
+        worst = max(worst, err)
+    assert np.radians(worst) < 1e-3  # the tolerance the orientation is held to
+
+
+def test_ic_moments_match_definition_and_symmetry():
+    img = synth.textured_canvas(80, 70, 19)
+    for cx, cy in ((31, 31), (40, 35), (48, 38)):
+        assert O.ic_moments(img, cx, cy) == S.ic_moments(img, cx, cy)
+    flat = np.full((40, 40), 9, np.uint8)
+    assert O.ic_moments(flat, 20, 20) == (0, 0)
+    right = np.zeros((40, 40), np.uint8)
+    right[:, 21:] = 200  # all mass to the right -> angle ~ 0
+    assert abs(((O.ic_angle(right, 20, 20) + 180) % 360) - 180) < 1e-3
+    down = np.zeros((40, 40), np.uint8)
+    down[21:, :] = 200
+    assert abs(O.ic_angle(down, 20, 20) - 90) < 1e-3
+
+
+def test_sincos_contract_is_correctly_rounded_and_near_libm():
+    diff = 0
+    n = 0
+    for i in range(-3600, 7200):
+        ang = np.float32(i * 0.1)
+        s, c = O.sincos_deg(ang, 0)
+        theta = np.float64(np.float32(ang) * np.float32(np.pi / 180.0))
+        assert s == np.float32(np.sin(theta)) and c == np.float32(np.cos(theta)), ang
+        s2, c2 = O.sincos_deg(ang, 1)
+        diff += (s != s2) + (c != c2)
+        n += 2
+    assert diff <= n * 3 // 100  # libm cosf/sinf differ in the last bit in ~1 % of cases
+
+
+# ------------------------------------------------------------ descriptor
+def test_brief_constant_image_is_zero():
+    img = np.full((80, 80), 123, np.uint8)
+    assert not O.brief256(img, 40, 40, 33.0).any()
+
+
+@pytest.mark.parametrize("angle", [-1.0, 0.0, 12.5, 90.0, 179.99, 271.3, 359.9])
+def test_brief_matches_slow_definition(angle):
+    img = O.blur7(synth.textured_canvas(90, 90, 21))
+    for cx, cy in ((31, 31), (45, 50), (58, 58)):
+        assert np.array_equal(O.brief256(img, cx, cy, angle), S.brief256(img, cx, cy, angle, PATTERN))
+
+
+def test_brief_bit_order():
+    # one bright pixel at the second point of test 0 (9,5) -> bit 0 of byte 0
+    img = np.zeros((80, 80), np.uint8)
+    img[40 + 5, 40 + 9] = 255
+    d = O.brief256(img, 40, 40, 0.0)
+    assert d[0] & 1
+    hits = [(t >> 3, t & 7) for t in range(256) if tuple(PATTERN[t, 2:4]) == (9, 5)
+            and tuple(PATTERN[t, 0:2]) != (9, 5)]
+    want = np.zeros(32, np.uint8)
+    for byte, bit in hits:
+        want[byte] |= 1 << bit
+    assert np.array_equal(d, want)
+
+
+# -------------------------------------------------------------- matching
+def test_knn2_known_answers():
+    a = np.zeros((1, 32), np.uint8)
+    t = np.zeros((3, 32), np.uint8)
+    t[0] = 255  # complement: 256
+    t[1, 0] = 0b111  # 3
+    t[2, 5] = 0b10101  # 3: tie -> lower index first
+    m = O.match_knn2(a, t)[0]
+    assert (m["idx0"], m["idx1"], m["d0"], m["d1"], m["nfound"]) == (1, 2, 3, 3, 2)
+    assert m["ratio_pass"] == 0
+    m = O.match_knn2(a, t[:1])[0]
+    assert (m["idx0"], m["idx1"], m["d0"], m["nfound"], m["ratio_pass"]) == (0, -1, 256, 1, 0)
+    assert len(O.match_knn2(np.zeros((0, 32), np.uint8), t)) == 0
+    m = O.match_knn2(a, np.zeros((0, 32), np.uint8))[0]
+    assert (m["idx0"], m["idx1"], m["nfound"]) == (-1, -1, 0)
+
+
+def test_knn2_ratio_is_exact_integer_rule():
+    # d0 < 0.75f*d1  <=>  4*d0 < 3*d1 for all 0..256
+    for d1 in range(257):
+        for d0 in range(d1 + 1):
+            assert (np.float32(d0) < np.float32(0.75) * np.float32(d1)) == (4 * d0 < 3 * d1)
+
+
+def test_knn2_matches_stable_argsort():
+    q, t = synth.descriptor_sets(150, 400, seed=3, dup_percent=5)
+    got = O.match_knn2(q, t)
+    want = S.knn2(q, t)
+    for g, w in zip(got, want):
+        assert (g["idx0"], g["idx1"], g["d0"], g["d1"], g["ratio_pass"]) == w
+    assert got["ratio_pass"].sum() > 20
+    assert (got["d0"] == got["d1"]).sum() > 0  # duplicates exercised the tie-break
+
+
+# ------------------------------------------------- search by projection
+def _projection_case(nk=120, npts=300, seed=31):
+    fd = synth.random_descriptors(nk, seed, 2)
+    xy = np.stack([synth.rand_below(seed, 70, np.arange(nk), 200),
+                   synth.rand_below(seed, 71, np.arange(nk), 150)], 1).astype(np.float32)
+    uv, pd = synth.local_map(fd, xy, npts, 200, 150, seed)
+    ids = np.arange(1000, 1000 + npts, dtype=np.int32)
+    inl = synth.rand_below(seed, 72, np.arange(80), nk).astype(np.int32)
+    return xy, fd, inl, uv, pd, ids
+
+
+def test_search_by_projection_matches_literal_loop():
+    xy, fd, inl, uv, pd, ids = _projection_case()
+    got = O.search_by_projection(xy, fd, inl, uv, pd, ids)
+    want = S.search_by_projection(xy, fd, inl, uv, pd, ids)
+    assert np.array_equal(got, want)
+    assert (got >= 0).sum() > 10
+    hit = got[got >= 0]
+    assert len(set(hit.tolist())) == len(hit)  # a map point is consumed once
+
+
+def test_search_by_projection_greedy_order_matters():
+    # two keypoints compete for one map point: the first inlier takes it
+    fd = np.zeros((2, 32), np.uint8)
+    xy = np.array([[10, 10], [11, 10]], np.float32)
+    uv = np.array([[10.5, 10.0]], np.float32)
+    pd = np.zeros((1, 32), np.uint8)
+    ids = np.array([7], np.int32)
+    assert list(O.search_by_projection(xy, fd, [0, 1], uv, pd, ids)) == [7, -1]
+    assert list(O.search_by_projection(xy, fd, [1, 0], uv, pd, ids)) == [7, -1]
+    assert list(O.search_by_projection(xy, fd, [0], uv[:0], pd[:0], ids[:0])) == [-1]
+
+
+def test_search_by_projection_gates():
+    fd = np.zeros((1, 32), np.uint8)
+    xy = np.array([[100, 100]], np.float32)
+    pd = np.zeros((3, 32), np.uint8)
+    pd[0, :16] = 255  # hamming 128: accepted (<=)
+    pd[1, :16] = 255
+    pd[1, 16] = 1  # 129: rejected
+    uv = np.array([[132, 100], [100, 100], [100, 132.001]], np.float32)  # 32 ok, -, >32
+    ids = np.array([0, 1, 2], np.int32)
+    assert list(O.search_by_projection(xy, fd, [0], uv, pd, ids)) == [0]
+    assert list(O.search_by_projection(xy, fd, [0], uv[1:], pd[1:], ids[1:])) == [-1]
+
+
+# --------------------------------------------------------------- extract
+def _compose_mode_orb(img, thr, nfeat):
+    """Full ORB composed from the slow definitions."""
+    lw, lh, ls = O.level_geometry(img.shape[1], img.shape[0])
+    quota = O.level_quotas(nfeat)
+    rows = []
+    level = img
+    for l in range(8):
+        if l:
+            level = S.resize_linear_exact(level, int(lw[l]), int(lh[l]))
+        c = S.fast_nms(level, thr)
+        W, H = int(lw[l]), int(lh[l])
+        c = c[(c[:, 0] >= 31) & (c[:, 0] < W - 31) & (c[:, 1] >= 31) & (c[:, 1] < H - 31)]
+        if len(c) > quota[l]:
+            cut = np.sort(c[:, 2])[::-1][quota[l] - 1] if quota[l] else 1 << 30
+            c = c[c[:, 2] >= cut]
+        blurred = S.blur7(level)
+        for x, y, s in c:
+            m10, m01 = S.ic_moments(level, x, y)
+            ang = O.fast_atan2(np.float32(m01), np.float32(m10))
+            d = S.brief256(blurred, x, y, ang, PATTERN)
+            rows.append((np.float32(x) * ls[l], np.float32(y) * ls[l], l, s, ang, d))
+    return rows
+
+
+def test_extract_mode_orb_matches_composition():
+    img = synth.textured_canvas(200, 160, 23)
+    p = abi.reference_params(fast_threshold=20, nfeatures=60)
+    kps, desc = O.extract(p, img)
+    want = _compose_mode_orb(img, 20, 60)
+    assert len(kps) == len(want) and 30 <= len(kps) < 116  # the quota cut is exercised
+    for k, d, w in zip(kps, desc, want):
+        assert (k["x"], k["y"], k["octave"], k["response"]) == (w[0], w[1], w[2], w[3])
+        assert k["angle"] == np.float32(w[4])
+        assert k["size"] == np.float32(31) * O.level_geometry(200, 160)[2][w[2]]
+        assert np.array_equal(d, w[5])
+    assert len(set(kps["octave"])) >= 3
+
+
+def test_extract_mode_provided_is_fast_then_compute():
+    img = synth.textured_canvas(160, 120, 24)
+    p = abi.reference_params(mode=abi.MODE_PROVIDED, fast_threshold=30)
+    kps, desc = O.extract(p, img)
+    c = S.fast_nms(img, 30)
+    c = c[(c[:, 0] >= 31) & (c[:, 0] < 160 - 31) & (c[:, 1] >= 31) & (c[:, 1] < 120 - 31)]
+    assert len(kps) == len(c) > 10
+    blurred = S.blur7(img)
+    for k, d, (x, y, s) in zip(kps, desc, c):
+        assert (k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"],
+                k["class_id"]) == (x, y, 7, -1, s, 0, -1)
+        assert np.array_equal(d, S.brief256(blurred, x, y, -1.0, PATTERN))
+
+
+def test_extract_bgr_equals_gray_of_same_frame():
+    g = synth.textured_canvas(128, 100, 25)
+    bgr = np.stack([g, g, g], axis=2)  # weights sum to 2^14: gray of (g,g,g) is g
+    p = abi.reference_params(fast_threshold=20, nfeatures=100)
+    k1, d1 = O.extract(p, g)
+    k2, d2 = O.extract(p, bgr)
+    assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
+
+
+def test_benchmark_frame_saturates_every_level_quota():
+    a, _ = synth.frame_pair(640, 480)
+    p = abi.reference_params(fast_threshold=20, nfeatures=2000)
+    kps, _ = O.extract(p, a)
+    assert np.all(np.bincount(kps["octave"], minlength=8) >= O.level_quotas(2000))
+
+
+def test_libm_trig_changes_few_descriptor_bits():
+    a, _ = synth.frame_pair(640, 480)
+    p = abi.reference_params(fast_threshold=20, nfeatures=2000)
+    _, d0 = O.extract(p, a, trig_mode=0)
+    _, d1 = O.extract(p, a, trig_mode=1)
+    bits = int(np.unpackbits(d0 ^ d1).sum())
+    assert bits <= d0.size * 8 // 10000  # reported delta: < 0.01 % of bits
