@@ -194,6 +194,13 @@ int slamfe_sync(slamfe_ctx* ctx);
 int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamfe_keypoint** d_kps,
                              const uint8_t** d_desc, const int32_t** d_count);
 
+/* Test hook (no counterpart in the reference): copy pyramid level `level` of
+ * frame `frame_in_batch` of the most recent extraction to the host, either
+ * the unblurred level (blurred = 0: what FAST and the orientation read) or the
+ * blurred one (what the descriptors read).  out: *h rows of *w bytes. */
+int slamfe_debug_read_level(slamfe_ctx* ctx, int frame_in_batch, int level, int blurred,
+                            uint8_t* out, int out_capacity, int* w, int* h);
+
 /* Library version, for the loader's sanity check. */
 int slamfe_version(void);
 

@@ -1,0 +1,709 @@
+// slamfe_api.hip -- host side of libslamfe.so: the C ABI of include/slamfe.h.
+//
+// A context owns one GPU, one stream and every device buffer the kernels use.
+// Device memory is laid out for a batch of `max_batch` frames:
+//
+//   pyr / blur      [max_batch][frame_bytes]    unblurred / blurred pyramids,
+//                                               level l at lv[l].off, rows of
+//                                               lv[l].pitch bytes (64-B aligned)
+//   cand            [max_batch][tiles][256] u32 FAST survivors per 64x16 tile
+//   hist            [max_batch][levels][256]    score histograms
+//   frame slots     [frame_slots][max_kp]       keys, levels, cv::KeyPoint
+//                                               records, 32-byte descriptor rows
+//   map_desc        [map_capacity][32]          mirror of Point::desc
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "slamfe.h"
+#include "slamfe_dev.h"
+#include "slamfe_kernels.h"
+#include "slamfe_math.h"
+
+namespace {
+
+struct Scratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct slamfe_ctx {
+    slamfe_params p;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // geometry of the frame size in use
+    int gw = 0, gh = 0;
+    slamfe_dev_geom geom;
+    std::vector<uint32_t> taps_host;
+    size_t sort_lds = 0;
+    // upper bounds from (max_width, max_height)
+    size_t cap_frame_bytes = 0;
+    int cap_tiles = 0, cap_bands = 0;
+    size_t cap_taps = 0;
+
+    uint8_t *pyr = nullptr, *blur = nullptr, *in_stage = nullptr;
+    uint32_t* taps = nullptr;
+    uint32_t *cand = nullptr, *cand_cnt = nullptr, *hist = nullptr, *band_cnt = nullptr,
+             *level_kept = nullptr;
+    int32_t* level_cutoff = nullptr;
+
+    int max_kp = 0, nslots = 0;
+    uint32_t *kp_key = nullptr, *kp_level = nullptr;
+    int32_t* kp_count = nullptr;
+    slamfe_keypoint* kps = nullptr;
+    uint8_t* desc = nullptr;
+    std::vector<uint64_t> slot_handle;
+    uint64_t next_seq = 1; // handle = sequence number; slot = seq % nslots
+
+    slamfe_match2* match_out = nullptr; // [max_kp]
+    int fm_qpt = 1, fm_chunk = 64, fm_nchunks = 1; // plan for frame-vs-frame matching
+    Scratch match_part, match_q, match_t, match_o;
+    uint8_t* map_desc = nullptr;
+    Scratch pj_idx, pj_uv, pj_ids, pj_cand, pj_candn, pj_matched;
+};
+
+namespace {
+
+int fail(slamfe_ctx* c, int code, const char* fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), SLAMFE_E_DEVICE, "%s failed: %s (%s:%d)", #call,               \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+#define KCHK(c, call)                                                                       \
+    do {                                                                                    \
+        int e_ = (call);                                                                    \
+        if (e_ != 0)                                                                        \
+            return fail((c), SLAMFE_E_DEVICE, "%s failed: %s", #call,                       \
+                        hipGetErrorString((hipError_t)e_));                                 \
+    } while (0)
+
+int grow(slamfe_ctx* c, Scratch& s, size_t bytes)
+{
+    if (bytes <= s.bytes) return SLAMFE_OK;
+    if (s.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(s.p));
+        s.p = nullptr;
+        s.bytes = 0;
+    }
+    size_t want = bytes + bytes / 2 + 256;
+    HIPCHK(c, hipMalloc(&s.p, want));
+    s.bytes = want;
+    return SLAMFE_OK;
+}
+
+// Per-axis taps of the fixed-point bilinear resize: source offset and the 8.8
+// weight of the right/lower tap, packed as ofs | c1 << 16.  The sample
+// position is scale * (d + 0.5) - 0.5 in double with scale = 1 / (dst / src).
+void resize_taps(int ssize, int dsize, uint32_t* out)
+{
+    double inv_scale = (double)dsize / (double)ssize;
+    double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dsize; ++d) {
+        double f = scale * ((double)d + 0.5) - 0.5;
+        int i0 = (int)floor(f);
+        uint32_t ofs = 0, c1 = 0;
+        if (i0 >= 0 && ssize > 1) {
+            if (i0 < ssize - 1) {
+                ofs = (uint32_t)i0;
+                c1 = (uint32_t)slamfe_round_d((f - (double)i0) * 256.0);
+            } else {
+                ofs = (uint32_t)(ssize - 1);
+            }
+        }
+        out[d] = ofs | (c1 << 16);
+    }
+}
+
+// Level sizes, scales and retain-best quotas as cv::ORB computes them
+// (Init.cc:65: nfeatures, 1.2f, 8 levels), plus the device layout.
+void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
+                    std::vector<uint32_t>* taps)
+{
+    memset(g, 0, sizeof *g);
+    int nlevels = p.mode == SLAMFE_MODE_PROVIDED ? 1 : p.nlevels;
+    g->nlevels = nlevels;
+    // quotas
+    int quota[SLAMFE_MAX_LEVELS];
+    if (p.mode == SLAMFE_MODE_ORB) {
+        float factor = (float)(1.0 / (double)p.scale_factor);
+        float nd = (float)p.nfeatures * (1 - factor) /
+                   (1 - (float)pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int l = 0; l < nlevels - 1; ++l) {
+            quota[l] = slamfe_round_f(nd);
+            sum += quota[l];
+            nd *= factor;
+        }
+        quota[nlevels - 1] = p.nfeatures - sum > 0 ? p.nfeatures - sum : 0;
+    } else {
+        quota[0] = INT32_MAX;
+    }
+    uint32_t off = 0;
+    int tiles = 0, bands = 0;
+    size_t ntaps = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        slamfe_dev_level& L = g->lv[l];
+        float scale = (float)pow((double)p.scale_factor, (double)l);
+        float inv = 1.0f / scale;
+        L.scale = scale;
+        L.w = slamfe_round_f((float)w * inv);
+        L.h = slamfe_round_f((float)h * inv);
+        L.pitch = (L.w + 63) / 64 * 64;
+        L.quota = quota[l];
+        L.off = off;
+        off += (uint32_t)L.pitch * (uint32_t)L.h;
+        off = (off + 255u) & ~255u;
+        L.tiles_x = (L.w + SLAMFE_TILE_W - 1) / SLAMFE_TILE_W;
+        L.tiles_y = (L.h + SLAMFE_TILE_H - 1) / SLAMFE_TILE_H;
+        L.tile_base = tiles;
+        L.band_base = bands;
+        tiles += L.tiles_x * L.tiles_y;
+        bands += L.tiles_y;
+        L.tap_x = (uint32_t)ntaps;
+        ntaps += (size_t)L.w;
+        L.tap_y = (uint32_t)ntaps;
+        ntaps += (size_t)L.h;
+    }
+    g->frame_bytes = off;
+    g->total_tiles = tiles;
+    g->total_bands = bands;
+    if (taps) {
+        taps->assign(ntaps, 0u);
+        for (int l = 1; l < nlevels; ++l) {
+            resize_taps(g->lv[l - 1].w, g->lv[l].w, taps->data() + g->lv[l].tap_x);
+            resize_taps(g->lv[l - 1].h, g->lv[l].h, taps->data() + g->lv[l].tap_y);
+        }
+    }
+}
+
+size_t sort_lds_bytes_for(const slamfe_dev_geom& g)
+{
+    size_t n = 1;
+    for (int l = 0; l < g.nlevels; ++l) {
+        size_t need = (size_t)g.lv[l].tiles_x * SLAMFE_TILE_CAND;
+        while (n < need) n <<= 1;
+    }
+    return n * sizeof(uint32_t);
+}
+
+int ensure_geometry(slamfe_ctx* c, int w, int h)
+{
+    if (w == c->gw && h == c->gh) return SLAMFE_OK;
+    if (w < 1 || h < 1 || w > c->p.max_width || h > c->p.max_height)
+        return fail(c, SLAMFE_E_INVALID, "frame %dx%d outside the context's maximum %dx%d", w, h,
+                    c->p.max_width, c->p.max_height);
+    slamfe_dev_geom g;
+    std::vector<uint32_t> taps;
+    build_geometry(c->p, w, h, &g, &taps);
+    if (g.frame_bytes > c->cap_frame_bytes || g.total_tiles > c->cap_tiles ||
+        g.total_bands > c->cap_bands || taps.size() > c->cap_taps)
+        return fail(c, SLAMFE_E_CAPACITY, "internal: geometry of %dx%d exceeds buffers", w, h);
+    // the previous taps may still be in use by queued kernels
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->taps_host.swap(taps);
+    if (!c->taps_host.empty())
+        HIPCHK(c, hipMemcpy(c->taps, c->taps_host.data(), c->taps_host.size() * sizeof(uint32_t),
+                            hipMemcpyHostToDevice));
+    c->geom = g;
+    c->sort_lds = sort_lds_bytes_for(g);
+    c->gw = w;
+    c->gh = h;
+    return SLAMFE_OK;
+}
+
+int slot_of(const slamfe_ctx* c, uint64_t handle)
+{
+    if (handle == 0) return -1;
+    int s = (int)(handle % (uint64_t)c->nslots);
+    return c->slot_handle[s] == handle ? s : -1;
+}
+
+// Queue the whole extraction of n device-resident frames.
+int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int stride,
+                size_t frame_stride, int channels, uint64_t* handles)
+{
+    if (n < 1 || n > c->p.max_batch)
+        return fail(c, SLAMFE_E_INVALID, "batch of %d frames; context allows 1..%d", n,
+                    c->p.max_batch);
+    if (channels != 1 && channels != 3)
+        return fail(c, SLAMFE_E_INVALID, "channels must be 1 (gray) or 3 (BGR), got %d", channels);
+    if (stride < w * channels) return fail(c, SLAMFE_E_INVALID, "stride %d < row bytes", stride);
+    int rc = ensure_geometry(c, w, h);
+    if (rc) return rc;
+    const slamfe_dev_geom& g = c->geom;
+    hipStream_t s = c->stream;
+    uint64_t seq0 = c->next_seq;
+    int slot_base = (int)(seq0 % (uint64_t)c->nslots);
+    for (int i = 0; i < n; ++i) {
+        uint64_t hdl = seq0 + (uint64_t)i;
+        c->slot_handle[(size_t)(hdl % (uint64_t)c->nslots)] = hdl;
+        if (handles) handles[i] = hdl;
+    }
+    c->next_seq += (uint64_t)n;
+
+    HIPCHK(c, hipMemsetAsync(c->hist, 0, (size_t)n * g.nlevels * 256 * sizeof(uint32_t), s));
+    KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
+                                 g.frame_bytes, g.lv[0].pitch));
+    KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
+    KCHK(c, slamfe_launch_fast(s, g, n, c->pyr, c->p.fast_threshold, c->p.edge_threshold, c->cand,
+                               c->cand_cnt, c->hist));
+    KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->hist, c->band_cnt, c->level_kept,
+                                 c->level_cutoff, slot_base, c->nslots, c->kp_key, c->kp_level,
+                                 c->kp_count, c->max_kp, c->sort_lds));
+    KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
+                                 c->kp_count, c->kps, c->max_kp, c->p.mode, c->p.patch_size));
+    KCHK(c, slamfe_launch_blur(s, g, n, c->pyr, c->blur));
+    KCHK(c, slamfe_launch_describe(s, g, n, c->blur, slot_base, c->nslots, c->kp_key, c->kp_level,
+                                   c->kp_count, c->kps, c->desc, c->max_kp));
+    return SLAMFE_OK;
+}
+
+int download_frame(slamfe_ctx* c, int slot, slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    int32_t n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, c->kp_count + slot, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = n;
+    if (n > c->max_kp)
+        return fail(c, SLAMFE_E_CAPACITY,
+                    "%d keypoints exceed the context's max_keypoints %d", n, c->max_kp);
+    if ((kps || desc) && n > cap)
+        return fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the caller's capacity %d", n, cap);
+    if (n > 0 && kps)
+        HIPCHK(c, hipMemcpyAsync(kps, c->kps + (size_t)slot * c->max_kp, (size_t)n * sizeof *kps,
+                                 hipMemcpyDeviceToHost, c->stream));
+    if (n > 0 && desc)
+        HIPCHK(c, hipMemcpyAsync(desc, c->desc + (size_t)slot * c->max_kp * 32, (size_t)n * 32,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SLAMFE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int slamfe_version(void) { return 100; }
+
+int slamfe_default_params(slamfe_params* p)
+{
+    if (!p) return SLAMFE_E_INVALID;
+    memset(p, 0, sizeof *p);
+    p->struct_size = (int32_t)sizeof *p;
+    p->mode = SLAMFE_MODE_ORB;
+    p->fast_threshold = 30; // main.cc:11
+    p->nfeatures = 10000;   // main.cc:11
+    p->scale_factor = 1.2f; // Init.cc:65
+    p->nlevels = 8;
+    p->edge_threshold = 31;
+    p->patch_size = 31;
+    p->ratio = 0.75f; // Init.cc:146
+    p->device_id = 0;
+    p->max_width = 1920;
+    p->max_height = 1080;
+    p->max_batch = 1;
+    p->max_keypoints = 0; // chosen from mode / nfeatures
+    p->frame_slots = 0;   // chosen from max_batch
+    p->map_capacity = 1 << 16;
+    p->stream = nullptr;
+    return SLAMFE_OK;
+}
+
+void slamfe_destroy(slamfe_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->p.device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->pyr, c->blur, c->in_stage, c->taps, c->cand, c->cand_cnt, c->hist,
+                    c->band_cnt, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
+                    c->kp_count, c->kps, c->desc, c->match_out, c->map_desc, c->match_part.p,
+                    c->match_q.p, c->match_t.p, c->match_o.p, c->pj_idx.p, c->pj_uv.p,
+                    c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* slamfe_last_error(const slamfe_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
+{
+    if (!pin || !out) return SLAMFE_E_INVALID;
+    *out = nullptr;
+    if (pin->struct_size != (int32_t)sizeof(slamfe_params)) return SLAMFE_E_INVALID;
+    slamfe_params p = *pin;
+    if (p.mode != SLAMFE_MODE_ORB && p.mode != SLAMFE_MODE_PROVIDED) return SLAMFE_E_INVALID;
+    if (p.nlevels < 1 || p.nlevels > SLAMFE_MAX_LEVELS) return SLAMFE_E_INVALID;
+    if (p.patch_size != 31 || p.edge_threshold < 19) return SLAMFE_E_INVALID;
+    if (!(p.scale_factor > 1.0f) || p.scale_factor > 2.0f) return SLAMFE_E_INVALID;
+    if (p.max_width < 8 || p.max_height < 8 || p.max_width > SLAMFE_MAX_DIM ||
+        p.max_height > SLAMFE_MAX_DIM)
+        return SLAMFE_E_INVALID;
+    if (p.max_batch < 1 || p.nfeatures < 0 || p.map_capacity < 0) return SLAMFE_E_INVALID;
+    if (p.fast_threshold < 0) p.fast_threshold = 0;
+    if (p.fast_threshold > 255) p.fast_threshold = 255;
+    if (p.max_keypoints <= 0)
+        p.max_keypoints = p.mode == SLAMFE_MODE_ORB ? (2 * p.nfeatures > 4096 ? 2 * p.nfeatures : 4096)
+                                                    : 32768;
+    if (p.max_keypoints >= SLAMFE_MAX_TRAIN) return SLAMFE_E_INVALID;
+    if (p.frame_slots <= 0) p.frame_slots = 2 * p.max_batch > 4 ? 2 * p.max_batch : 4;
+    if (p.frame_slots < p.max_batch) return SLAMFE_E_INVALID;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p.device_id < 0 ||
+        p.device_id >= ndev)
+        return SLAMFE_E_DEVICE;
+    if (hipSetDevice(p.device_id) != hipSuccess) return SLAMFE_E_DEVICE;
+
+    slamfe_ctx* c = new slamfe_ctx();
+    c->p = p;
+    c->max_kp = p.max_keypoints;
+    c->nslots = p.frame_slots;
+    c->slot_handle.assign((size_t)c->nslots, 0);
+    *out = c; // returned even on failure so that slamfe_last_error can be read
+    if (p.stream) {
+        c->stream = (hipStream_t)p.stream;
+    } else {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    slamfe_dev_geom gmax;
+    std::vector<uint32_t> tmax;
+    build_geometry(p, p.max_width, p.max_height, &gmax, &tmax);
+    c->cap_frame_bytes = (size_t)gmax.frame_bytes + 4096;
+    c->cap_tiles = gmax.total_tiles + 2 * SLAMFE_MAX_LEVELS + 64;
+    c->cap_bands = gmax.total_bands + SLAMFE_MAX_LEVELS;
+    c->cap_taps = tmax.size() + 64;
+    KCHK(c, slamfe_kernels_init(sort_lds_bytes_for(gmax)));
+
+    const size_t B = (size_t)p.max_batch;
+    HIPCHK(c, hipMalloc(&c->pyr, B * c->cap_frame_bytes));
+    HIPCHK(c, hipMalloc(&c->blur, B * c->cap_frame_bytes));
+    HIPCHK(c, hipMalloc(&c->in_stage, B * (size_t)p.max_width * p.max_height * 3));
+    HIPCHK(c, hipMalloc(&c->taps, c->cap_taps * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->cand, B * c->cap_tiles * SLAMFE_TILE_CAND * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->cand_cnt, B * c->cap_tiles * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->hist, B * SLAMFE_MAX_LEVELS * 256 * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->band_cnt, B * c->cap_bands * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->level_kept, B * SLAMFE_MAX_LEVELS * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->level_cutoff, B * SLAMFE_MAX_LEVELS * sizeof(int32_t)));
+    const size_t S = (size_t)c->nslots, K = (size_t)c->max_kp;
+    HIPCHK(c, hipMalloc(&c->kp_key, S * K * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->kp_level, S * K * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->kp_count, S * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->kps, S * K * sizeof(slamfe_keypoint)));
+    HIPCHK(c, hipMalloc(&c->desc, S * K * 32));
+    HIPCHK(c, hipMemset(c->kp_count, 0, S * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->match_out, K * sizeof(slamfe_match2)));
+    slamfe_match_plan(c->max_kp, c->max_kp, &c->fm_qpt, &c->fm_chunk, &c->fm_nchunks);
+    int rc = grow(c, c->match_part, (size_t)c->fm_nchunks * K * 8);
+    if (rc) return rc;
+    if (p.map_capacity > 0) {
+        HIPCHK(c, hipMalloc(&c->map_desc, (size_t)p.map_capacity * 32));
+        HIPCHK(c, hipMemset(c->map_desc, 0, (size_t)p.map_capacity * 32));
+    }
+    HIPCHK(c, hipDeviceSynchronize());
+    return SLAMFE_OK;
+}
+
+int slamfe_sync(slamfe_ctx* c)
+{
+    if (!c) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SLAMFE_OK;
+}
+
+int slamfe_extract_resident(slamfe_ctx* c, const void* d_imgs, int n, int w, int h, int stride,
+                            size_t frame_stride_bytes, int channels, uint64_t* frame_handles)
+{
+    if (!c || !d_imgs) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    return run_extract(c, (const uint8_t*)d_imgs, n, w, h, stride, frame_stride_bytes, channels,
+                       frame_handles);
+}
+
+int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride,
+                         int channels, slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                         uint64_t* frame_handles)
+{
+    if (!c || !imgs) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    if (n < 1 || n > c->p.max_batch)
+        return fail(c, SLAMFE_E_INVALID, "batch of %d frames; context allows 1..%d", n,
+                    c->p.max_batch);
+    if (w < 1 || h < 1 || w > c->p.max_width || h > c->p.max_height || (channels != 1 && channels != 3) ||
+        stride < w * channels)
+        return fail(c, SLAMFE_E_INVALID, "bad frame description %dx%d stride %d channels %d", w, h,
+                    stride, channels);
+    const size_t row = (size_t)w * channels, fbytes = row * h;
+    for (int i = 0; i < n; ++i) {
+        if (!imgs[i]) return fail(c, SLAMFE_E_INVALID, "imgs[%d] is NULL", i);
+        HIPCHK(c, hipMemcpy2DAsync(c->in_stage + (size_t)i * fbytes, row, imgs[i], (size_t)stride, row,
+                                   (size_t)h, hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<uint64_t> hd((size_t)n);
+    int rc = run_extract(c, c->in_stage, n, w, h, (int)row, fbytes, channels, hd.data());
+    if (rc) return rc;
+    int worst = SLAMFE_OK;
+    for (int i = 0; i < n; ++i) {
+        if (frame_handles) frame_handles[i] = hd[(size_t)i];
+        int cnt = 0;
+        rc = download_frame(c, slot_of(c, hd[(size_t)i]), kps ? kps + (size_t)i * cap : nullptr,
+                            desc ? desc + (size_t)i * cap * 32 : nullptr, cap, &cnt);
+        if (n_out) n_out[i] = cnt;
+        if (rc == SLAMFE_E_DEVICE) return rc;
+        if (rc) worst = rc;
+    }
+    return worst;
+}
+
+int slamfe_extract(slamfe_ctx* c, const uint8_t* img, int w, int h, int stride, int channels,
+                   slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out, uint64_t* frame_handle)
+{
+    const uint8_t* one[1] = {img};
+    return slamfe_extract_batch(c, one, 1, w, h, stride, channels, kps, desc, cap, n_out,
+                                frame_handle);
+}
+
+int slamfe_frame_download(slamfe_ctx* c, uint64_t frame_handle, slamfe_keypoint* kps, uint8_t* desc,
+                          int cap, int* n_out)
+{
+    if (!c) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    int slot = slot_of(c, frame_handle);
+    if (slot < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle %llu expired or unknown",
+                              (unsigned long long)frame_handle);
+    return download_frame(c, slot, kps, desc, cap, n_out);
+}
+
+int slamfe_frame_device_ptrs(slamfe_ctx* c, uint64_t frame_handle, const slamfe_keypoint** d_kps,
+                             const uint8_t** d_desc, const int32_t** d_count)
+{
+    if (!c) return SLAMFE_E_INVALID;
+    int slot = slot_of(c, frame_handle);
+    if (slot < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle %llu expired or unknown",
+                              (unsigned long long)frame_handle);
+    if (d_kps) *d_kps = c->kps + (size_t)slot * c->max_kp;
+    if (d_desc) *d_desc = c->desc + (size_t)slot * c->max_kp * 32;
+    if (d_count) *d_count = c->kp_count + slot;
+    return SLAMFE_OK;
+}
+
+int slamfe_match_knn2(slamfe_ctx* c, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                      slamfe_match2* out)
+{
+    if (!c || nq < 0 || nt < 0 || (nq > 0 && (!query || !out)) || (nt > 0 && !train))
+        return SLAMFE_E_INVALID;
+    if (nt >= SLAMFE_MAX_TRAIN)
+        return fail(c, SLAMFE_E_INVALID, "train set of %d rows; at most %d per call", nt,
+                    SLAMFE_MAX_TRAIN - 1);
+    if (nq == 0) return SLAMFE_OK;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    int rc;
+    if ((rc = grow(c, c->match_q, (size_t)nq * 32))) return rc;
+    if ((rc = grow(c, c->match_t, (size_t)(nt > 0 ? nt : 1) * 32))) return rc;
+    if ((rc = grow(c, c->match_o, (size_t)nq * sizeof(slamfe_match2)))) return rc;
+    int qpt, chunk, nchunks;
+    slamfe_match_plan(nq, nt, &qpt, &chunk, &nchunks);
+    if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->match_q.p, query, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (nt > 0)
+        HIPCHK(c, hipMemcpyAsync(c->match_t.p, train, (size_t)nt * 32, hipMemcpyHostToDevice,
+                                 c->stream));
+    KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)c->match_q.p, nq, nullptr,
+                                (const uint8_t*)c->match_t.p, nt, nullptr, nq, qpt, chunk, nchunks,
+                                (uint32_t*)c->match_part.p, c->p.ratio, (slamfe_match2*)c->match_o.p,
+                                nullptr, 0));
+    HIPCHK(c, hipMemcpyAsync(out, c->match_o.p, (size_t)nq * sizeof(slamfe_match2),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SLAMFE_OK;
+}
+
+int slamfe_match_resident(slamfe_ctx* c, uint64_t query_frame, uint64_t train_frame,
+                          slamfe_match2* d_out)
+{
+    if (!c || !d_out) return SLAMFE_E_INVALID;
+    int sq = slot_of(c, query_frame), st = slot_of(c, train_frame);
+    if (sq < 0 || st < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown");
+    KCHK(c, slamfe_launch_match(c->stream, c->desc + (size_t)sq * c->max_kp * 32, 0, c->kp_count + sq,
+                                c->desc + (size_t)st * c->max_kp * 32, 0, c->kp_count + st, c->max_kp,
+                                c->fm_qpt, c->fm_chunk, c->fm_nchunks, (uint32_t*)c->match_part.p,
+                                c->p.ratio, d_out, nullptr, 0));
+    return SLAMFE_OK;
+}
+
+int slamfe_match_frames(slamfe_ctx* c, uint64_t query_frame, uint64_t train_frame, slamfe_match2* out,
+                        int cap, int* nq_out)
+{
+    if (!c) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    int rc = slamfe_match_resident(c, query_frame, train_frame, c->match_out);
+    if (rc) return rc;
+    int sq = slot_of(c, query_frame);
+    int32_t nq = 0;
+    HIPCHK(c, hipMemcpyAsync(&nq, c->kp_count + sq, sizeof nq, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nq > c->max_kp) nq = c->max_kp;
+    if (nq_out) *nq_out = nq;
+    if (out) {
+        if (nq > cap)
+            return fail(c, SLAMFE_E_CAPACITY, "%d match rows exceed the caller's capacity %d", nq, cap);
+        if (nq > 0) {
+            HIPCHK(c, hipMemcpyAsync(out, c->match_out, (size_t)nq * sizeof *out,
+                                     hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    return SLAMFE_OK;
+}
+
+int slamfe_match_shard_keys(slamfe_ctx* c, const void* d_query, int nq, const void* d_train, int nt,
+                            int64_t train_base, uint64_t* d_keys)
+{
+    if (!c || nq < 0 || nt < 0 || !d_keys || (nq > 0 && !d_query) || (nt > 0 && !d_train))
+        return SLAMFE_E_INVALID;
+    if (nt >= SLAMFE_MAX_TRAIN)
+        return fail(c, SLAMFE_E_INVALID, "shard of %d rows; at most %d per call", nt,
+                    SLAMFE_MAX_TRAIN - 1);
+    if (nq == 0) return SLAMFE_OK;
+    int qpt, chunk, nchunks, rc;
+    slamfe_match_plan(nq, nt, &qpt, &chunk, &nchunks);
+    if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
+    KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)d_query, nq, nullptr,
+                                (const uint8_t*)d_train, nt, nullptr, nq, qpt, chunk, nchunks,
+                                (uint32_t*)c->match_part.p, c->p.ratio, nullptr, d_keys, train_base));
+    return SLAMFE_OK;
+}
+
+int slamfe_merge_shard_keys(slamfe_ctx* c, const uint64_t* d_keys_all, int nshards, int nq,
+                            slamfe_match2* d_out)
+{
+    if (!c || !d_keys_all || !d_out || nshards < 1 || nq < 0) return SLAMFE_E_INVALID;
+    KCHK(c, slamfe_launch_merge_shard_keys(c->stream, d_keys_all, nshards, nq, c->p.ratio, d_out));
+    return SLAMFE_OK;
+}
+
+int slamfe_map_put(slamfe_ctx* c, const int32_t* point_ids, const uint8_t* desc32, int n)
+{
+    if (!c || n < 0 || (n > 0 && (!point_ids || !desc32))) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    for (int i = 0; i < n; ++i)
+        if (point_ids[i] < 0 || point_ids[i] >= c->p.map_capacity)
+            return fail(c, SLAMFE_E_CAPACITY, "point id %d outside map_capacity %d", point_ids[i],
+                        c->p.map_capacity);
+    // ids are dense and usually consecutive (Init.cc:296 uses m.getPointsSize()):
+    // copy runs of consecutive ids in one transfer each
+    int i = 0;
+    while (i < n) {
+        int j = i + 1;
+        while (j < n && point_ids[j] == point_ids[j - 1] + 1) ++j;
+        HIPCHK(c, hipMemcpyAsync(c->map_desc + (size_t)point_ids[i] * 32, desc32 + (size_t)i * 32,
+                                 (size_t)(j - i) * 32, hipMemcpyHostToDevice, c->stream));
+        i = j;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SLAMFE_OK;
+}
+
+int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n_inl,
+                                const float* uv, const int32_t* point_ids, int R, float radius,
+                                int max_hamming, int32_t* matched_point_id)
+{
+    if (!c || n_inl < 0 || R < 0 || (n_inl > 0 && (!kp_idx || !matched_point_id)) ||
+        (R > 0 && (!uv || !point_ids)))
+        return SLAMFE_E_INVALID;
+    if (R > SLAMFE_PROJ_MAX_POINTS)
+        return fail(c, SLAMFE_E_CAPACITY, "%d visible points; at most %d", R, SLAMFE_PROJ_MAX_POINTS);
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    int slot = slot_of(c, frame);
+    if (slot < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown");
+    if (n_inl == 0) return SLAMFE_OK;
+    if (R == 0) { // Init.cc:233: nothing to search
+        for (int i = 0; i < n_inl; ++i) matched_point_id[i] = -1;
+        return SLAMFE_OK;
+    }
+    for (int j = 0; j < R; ++j)
+        if (point_ids[j] < 0 || point_ids[j] >= c->p.map_capacity)
+            return fail(c, SLAMFE_E_INVALID, "point id %d outside map_capacity %d", point_ids[j],
+                        c->p.map_capacity);
+    int32_t nkp = 0;
+    HIPCHK(c, hipMemcpyAsync(&nkp, c->kp_count + slot, sizeof nkp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nkp > c->max_kp) nkp = c->max_kp;
+    for (int i = 0; i < n_inl; ++i)
+        if (kp_idx[i] < 0 || kp_idx[i] >= nkp)
+            return fail(c, SLAMFE_E_INVALID, "kp_idx[%d] = %d outside the frame's %d keypoints", i,
+                        kp_idx[i], nkp);
+    int rc;
+    if ((rc = grow(c, c->pj_idx, (size_t)n_inl * 4))) return rc;
+    if ((rc = grow(c, c->pj_uv, (size_t)R * 8))) return rc;
+    if ((rc = grow(c, c->pj_ids, (size_t)R * 4))) return rc;
+    if ((rc = grow(c, c->pj_cand, (size_t)n_inl * SLAMFE_PROJ_K * 4))) return rc;
+    if ((rc = grow(c, c->pj_candn, (size_t)n_inl * 4))) return rc;
+    if ((rc = grow(c, c->pj_matched, (size_t)n_inl * 4))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->pj_idx.p, kp_idx, (size_t)n_inl * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->pj_uv.p, uv, (size_t)R * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->pj_ids.p, point_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    KCHK(c, slamfe_launch_projection(s, c->kps + (size_t)slot * c->max_kp,
+                                     c->desc + (size_t)slot * c->max_kp * 32, nkp,
+                                     (const int32_t*)c->pj_idx.p, n_inl, (const float*)c->pj_uv.p,
+                                     (const int32_t*)c->pj_ids.p, R, c->map_desc, radius, max_hamming,
+                                     (uint32_t*)c->pj_cand.p, (int32_t*)c->pj_candn.p,
+                                     (int32_t*)c->pj_matched.p));
+    HIPCHK(c, hipMemcpyAsync(matched_point_id, c->pj_matched.p, (size_t)n_inl * 4,
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return SLAMFE_OK;
+}
+
+int slamfe_debug_read_level(slamfe_ctx* c, int frame_in_batch, int level, int blurred, uint8_t* out,
+                            int out_capacity, int* w, int* h)
+{
+    if (!c || !out || c->gw == 0) return SLAMFE_E_INVALID;
+    if (frame_in_batch < 0 || frame_in_batch >= c->p.max_batch || level < 0 ||
+        level >= c->geom.nlevels)
+        return fail(c, SLAMFE_E_INVALID, "no such frame / level");
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    const slamfe_dev_level& L = c->geom.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if ((size_t)L.w * L.h > (size_t)out_capacity)
+        return fail(c, SLAMFE_E_CAPACITY, "level needs %d bytes", L.w * L.h);
+    const uint8_t* src = (blurred ? c->blur : c->pyr) + (size_t)frame_in_batch * c->geom.frame_bytes + L.off;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, src, (size_t)L.pitch, (size_t)L.w, (size_t)L.h,
+                          hipMemcpyDeviceToHost));
+    return SLAMFE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,52 @@
+/* slamfe_dev.h -- structures shared by the host library and the HIP kernels. */
+#ifndef SLAMFE_DEV_H
+#define SLAMFE_DEV_H
+
+#include <stdint.h>
+
+#define SLAMFE_MAX_LEVELS 8
+#define SLAMFE_MAX_DIM 4096
+
+/* FAST / blur tiles: 64 x 16 output pixels per workgroup of 256 threads.
+ * After 3x3 non-max suppression no two survivors are 8-neighbours, so a tile
+ * holds at most (64/2) * (16/2) = 256 of them. */
+#define SLAMFE_TILE_W 64
+#define SLAMFE_TILE_H 16
+#define SLAMFE_TILE_CAND 256
+
+/* One pyramid level of one frame.  All frames of a batch share the geometry;
+ * frame f, level l starts at pyr + f * frame_bytes + off. */
+typedef struct slamfe_dev_level {
+    int32_t w, h;        /* level size in pixels */
+    int32_t pitch;       /* bytes per row (multiple of 64) */
+    int32_t quota;       /* retain-best quota (INT32_MAX: keep all) */
+    uint32_t off;        /* byte offset of the level inside a frame's pyramid */
+    int32_t tiles_x, tiles_y;
+    int32_t tile_base;   /* index of the level's first tile in the frame's tile list */
+    int32_t band_base;   /* index of the level's first tile row ("band") */
+    float scale;         /* level scale factor (1, 1.2, 1.44, ...) */
+    uint32_t tap_x, tap_y; /* offsets (in uint32 entries) of the level's resize taps */
+    int32_t pad;
+} slamfe_dev_level;
+
+typedef struct slamfe_dev_geom {
+    int32_t nlevels;
+    int32_t total_tiles;
+    int32_t total_bands;
+    uint32_t frame_bytes; /* bytes of one frame's pyramid */
+    slamfe_dev_level lv[SLAMFE_MAX_LEVELS];
+} slamfe_dev_geom;
+
+/* Candidate / keypoint key: y in bits 31..20, x in bits 19..8, score in 7..0,
+ * so ascending keys are in (y, x) order. */
+#define SLAMFE_KEY(x, y, s) (((uint32_t)(y) << 20) | ((uint32_t)(x) << 8) | (uint32_t)(s))
+#define SLAMFE_KEY_X(k) (((k) >> 8) & 0xfffu)
+#define SLAMFE_KEY_Y(k) ((k) >> 20)
+#define SLAMFE_KEY_S(k) ((k) & 0xffu)
+
+/* Match keys inside one call: distance in bits 31..23, train row in 22..0. */
+#define SLAMFE_MKEY_SHIFT 23
+#define SLAMFE_MKEY_NONE 0xffffffffu
+#define SLAMFE_MAX_TRAIN (1 << SLAMFE_MKEY_SHIFT)
+
+#endif

@@ -1,0 +1,53 @@
+/* slamfe_kernels.h -- launchers of the HIP kernels (internal to libslamfe). */
+#ifndef SLAMFE_KERNELS_H
+#define SLAMFE_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "slamfe.h"
+#include "slamfe_dev.h"
+
+/* Every launcher returns 0 or a hipError_t value. */
+int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int stride,
+                         size_t frame_stride, int channels, int nframes, uint8_t* pyr,
+                         uint32_t frame_bytes, int pitch);
+int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
+                          const uint32_t* taps);
+int slamfe_launch_fast(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                       int thr, int edge, uint32_t* cand, uint32_t* cand_cnt, uint32_t* hist);
+int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,
+                         const uint32_t* cand_cnt, const uint32_t* hist, uint32_t* band_cnt,
+                         uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
+                         uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
+                         size_t sort_lds_bytes);
+int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                         int slot_base, int nslots, const uint32_t* kp_key,
+                         const uint32_t* kp_level, const int32_t* kp_count, slamfe_keypoint* kps,
+                         int max_kp, int mode, int patch_size);
+int slamfe_launch_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                       uint8_t* blur);
+int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* blur,
+                           int slot_base, int nslots, const uint32_t* kp_key,
+                           const uint32_t* kp_level, const int32_t* kp_count,
+                           const slamfe_keypoint* kps, uint8_t* desc, int max_kp);
+
+/* Choose queries per lane and the train chunking for a match of at most
+ * nq_max x nt_max rows; the partial buffer needs nchunks * cap * 8 bytes. */
+int slamfe_match_plan(int nq_max, int nt_max, int* qpt, int* chunk_rows, int* nchunks);
+int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int32_t* d_nq,
+                        const uint8_t* d_train, int nt, const int32_t* d_nt, int cap, int qpt,
+                        int chunk_rows, int nchunks, uint32_t* part, float ratio,
+                        slamfe_match2* d_out, uint64_t* d_keys, int64_t train_base);
+int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int nshards, int nq,
+                                   float ratio, slamfe_match2* d_out);
+
+#define SLAMFE_PROJ_K 32
+#define SLAMFE_PROJ_MAX_POINTS (1 << 20)
+int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
+                             const int32_t* kp_idx, int n_inl, const float* uv,
+                             const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
+                             int max_hamming, uint32_t* cand, int32_t* cand_n, int32_t* matched);
+int slamfe_kernels_init(size_t sort_lds_bytes);
+
+#endif

@@ -1,0 +1,990 @@
+// slamfe_kernels.hip -- gfx950 kernels of the feature front-end.
+//
+// Everything here is integer / byte work bound by HBM or by the integer VALU;
+// nothing is a dense contraction, so there is no MFMA.  Wavefronts are 64 wide.
+// Compile with -ffp-contract=off: the few float expressions (rotation of the
+// rBRIEF pattern, fastAtan2) are part of the numerical contract in
+// slamfe_math.h and must not be fused.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "slamfe.h"
+#include "slamfe_dev.h"
+#include "slamfe_kernels.h"
+#include "slamfe_math.h"
+#include "slamfe_tables.h"
+
+#define TW SLAMFE_TILE_W
+#define TH SLAMFE_TILE_H
+
+__device__ __constant__ int8_t c_pattern[1024] = SLAMFE_PATTERN_INIT;
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int find_level_by_tile(const slamfe_dev_geom& g, int t)
+{
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < SLAMFE_MAX_LEVELS; ++i)
+        if (i < g.nlevels && t >= g.lv[i].tile_base) l = i;
+    return l;
+}
+
+__device__ __forceinline__ int find_level_by_band(const slamfe_dev_geom& g, int b)
+{
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < SLAMFE_MAX_LEVELS; ++i)
+        if (i < g.nlevels && b >= g.lv[i].band_base) l = i;
+    return l;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    // valid for -n < i < 2n-1, which covers the 3-px reach of the blur
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i < 0 ? 0 : i;
+}
+
+// ---------------------------------------------------------------------------
+// K1  frame ingest: gray copy or BGR -> gray into pyramid level 0
+//     (cv::cvtColor(frame, frame, COLOR_BGR2GRAY), Init.cc:75)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ in, int w, int h,
+                                                int stride, size_t frame_stride, int channels,
+                                                uint8_t* __restrict__ pyr, uint32_t frame_bytes,
+                                                int pitch)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    int f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t* src = in + (size_t)f * frame_stride + (size_t)y * stride;
+    uint8_t v;
+    if (channels == 3) {
+        int b = src[3 * x], gg = src[3 * x + 1], r = src[3 * x + 2];
+        v = (uint8_t)((b * SLAMFE_B2Y + gg * SLAMFE_G2Y + r * SLAMFE_R2Y +
+                       (1 << (SLAMFE_GRAY_SHIFT - 1))) >> SLAMFE_GRAY_SHIFT);
+    } else {
+        v = src[x];
+    }
+    pyr[(size_t)f * frame_bytes + (size_t)y * pitch + x] = v;
+}
+
+// ---------------------------------------------------------------------------
+// K2  pyramid: level l from level l-1, INTER_LINEAR_EXACT fixed point
+//     taps: ofs | c1 << 16 per destination column / row (host-computed)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, uint8_t* __restrict__ pyr,
+                                                const uint32_t* __restrict__ taps)
+{
+    const slamfe_dev_level& S = g.lv[l - 1];
+    const slamfe_dev_level& D = g.lv[l];
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = blockIdx.z;
+    if (x >= D.w || y >= D.h) return;
+    const uint8_t* src = pyr + (size_t)f * g.frame_bytes + S.off;
+    uint8_t* dst = pyr + (size_t)f * g.frame_bytes + D.off;
+    uint32_t tx = taps[D.tap_x + x], ty = taps[D.tap_y + y];
+    uint32_t xo = tx & 0xffffu, c1 = tx >> 16, c0 = 256u - c1;
+    uint32_t yo = ty & 0xffffu, w1 = ty >> 16, w0 = 256u - w1;
+    uint32_t xo1 = xo + (c1 ? 1u : 0u), yo1 = yo + (w1 ? 1u : 0u);
+    const uint8_t* r0 = src + (size_t)yo * S.pitch;
+    const uint8_t* r1 = src + (size_t)yo1 * S.pitch;
+    uint32_t h0 = r0[xo] * c0 + r0[xo1] * c1;
+    uint32_t h1 = r1[xo] * c0 + r1[xo1] * c1;
+    uint32_t v = (h0 * w0 + h1 * w1 + (1u << 15)) >> 16;
+    dst[(size_t)y * D.pitch + x] = (uint8_t)(v > 255u ? 255u : v);
+}
+
+// ---------------------------------------------------------------------------
+// K3  FAST-9/16 segment test + score + strict 3x3 NMS + border filter
+//     (detector->detect, Init.cc:76; per level inside cv::ORB)
+//
+// One workgroup = one 64x16 tile.  The tile plus a 4-px halo is staged in
+// LDS, scores are computed for the tile plus a 1-px halo, NMS runs on the LDS
+// score tile.  Survivors inside the ORB border go to the tile's own candidate
+// list (no global atomics on lists; order inside a list is arbitrary and fixed
+// by the sort in k_select_write) and into the level's 256-bin score histogram.
+// ---------------------------------------------------------------------------
+#define FL_W (TW + 8)
+#define FL_H (TH + 8)
+#define FS_W (TW + 2)
+#define FS_H (TH + 2)
+
+__device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
+{
+    // ring pixel offsets in the LDS tile (pitch FL_W)
+    constexpr int R[16][2] = SLAMFE_FAST_RING_INIT;
+    int v = c[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[R[k][0] + R[k][1] * FL_W];
+    // min / max over every arc of 9 contiguous ring pixels:
+    // arc(s) = d[s..s+8] = three runs of three
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int a = d[k], b = d[(k + 1) & 15], e = d[(k + 2) & 15];
+        mn3[k] = min(a, min(b, e));
+        mx3[k] = max(a, max(b, e));
+    }
+    int A = INT_MIN, Bn = INT_MAX;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int mn9 = min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
+        int mx9 = max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
+        A = max(A, mn9);   // ring darker than centre by at least A on some arc
+        Bn = min(Bn, mx9); // ring brighter than centre by at least -Bn on some arc
+    }
+    int m = max(A, -Bn);
+    // corner <=> some arc has all |d| > thr on one side; score = that margin - 1
+    return m > thr ? m - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
+                                              int thr, int edge, uint32_t* __restrict__ cand,
+                                              uint32_t* __restrict__ cand_cnt,
+                                              uint32_t* __restrict__ hist)
+{
+    __shared__ uint8_t tile[FL_H * FL_W];
+    __shared__ uint8_t sc[FS_H * FS_W];
+    __shared__ uint32_t list[SLAMFE_TILE_CAND];
+    __shared__ uint32_t nlist;
+
+    const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int l = find_level_by_tile(g, t);
+    const slamfe_dev_level L = g.lv[l];
+    const int tl = t - L.tile_base;
+    const int x0 = (tl % L.tiles_x) * TW, y0 = (tl / L.tiles_x) * TH;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
+
+    if (tid == 0) nlist = 0;
+    for (int i = tid; i < FL_H * FL_W; i += 256) {
+        int ly = i / FL_W, lx = i - ly * FL_W;
+        int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+        uint8_t v = 0;
+        if (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) v = img[(size_t)gy * L.pitch + gx];
+        tile[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < FS_H * FS_W; i += 256) {
+        int sy = i / FS_W, sx = i - sy * FS_W;
+        int gy = y0 - 1 + sy, gx = x0 - 1 + sx;
+        int s = 0;
+        if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3)
+            s = fast_score_lds(&tile[(sy + 3) * FL_W + sx + 3], thr);
+        sc[i] = (uint8_t)s;
+    }
+    __syncthreads();
+    uint32_t* hl = hist + ((size_t)f * g.nlevels + l) * 256;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int py = (tid >> 6) + 4 * k, px = tid & 63;
+        const uint8_t* p = &sc[(py + 1) * FS_W + px + 1];
+        int s = p[0];
+        int m = max(max(max(p[-1], p[1]), max(p[-FS_W - 1], p[-FS_W])),
+                    max(max(p[-FS_W + 1], p[FS_W - 1]), max(p[FS_W], p[FS_W + 1])));
+        int gx = x0 + px, gy = y0 + py;
+        bool keep = s > m && gx >= edge && gx < L.w - edge && gy >= edge && gy < L.h - edge;
+        if (keep) {
+            uint32_t pos = atomicAdd(&nlist, 1u);
+            list[pos] = SLAMFE_KEY(gx, gy, s);
+            atomicAdd(&hl[s], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t n = nlist;
+    size_t tg = (size_t)f * g.total_tiles + t;
+    if (tid < n) cand[tg * SLAMFE_TILE_CAND + tid] = list[tid];
+    if (tid == 0) cand_cnt[tg] = n;
+}
+
+// ---------------------------------------------------------------------------
+// K4  keypoint selection (KeyPointsFilter::retainBest inside cv::ORB) and
+//     ordered compaction.
+//
+// Scores are integers below 256, so the retain-best cut-off is read from the
+// level's histogram: cut = the quota-th best score; every candidate with
+// score >= cut is kept (ties included).  Pass 1 counts kept candidates per
+// tile row ("band"); pass 2 turns the counts into offsets, sorts each band's
+// kept candidates by (y, x) in LDS and writes them in (level, y, x) order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void level_cut(const uint32_t* __restrict__ hl, int quota, uint32_t* sh,
+                                          int* cut_out, uint32_t* kept_out)
+{
+    // sh: 256 uint32 of LDS.  Inclusive suffix sum of the histogram.
+    const int tid = threadIdx.x;
+    sh[tid] = hl[tid];
+    __syncthreads();
+    for (int ofs = 1; ofs < 256; ofs <<= 1) {
+        uint32_t v = sh[tid] + (tid + ofs < 256 ? sh[tid + ofs] : 0u);
+        __syncthreads();
+        sh[tid] = v;
+        __syncthreads();
+    }
+    // suffix[s] = candidates with score >= s (non-increasing in s)
+    uint32_t total = sh[0];
+    int cut;
+    uint32_t kept;
+    if (total <= (uint32_t)quota) {
+        cut = 0;
+        kept = total;
+    } else if (quota <= 0) {
+        cut = 256;
+        kept = 0;
+    } else {
+        // largest s with suffix[s] >= quota = number of s with suffix[s] >= quota, minus 1
+        int c = __syncthreads_count(sh[tid] >= (uint32_t)quota);
+        cut = c - 1;
+        kept = sh[cut];
+    }
+    __syncthreads();
+    *cut_out = cut;
+    *kept_out = kept;
+}
+
+__global__ __launch_bounds__(256) void k_select_count(slamfe_dev_geom g,
+                                                      const uint32_t* __restrict__ cand,
+                                                      const uint32_t* __restrict__ cand_cnt,
+                                                      const uint32_t* __restrict__ hist,
+                                                      uint32_t* __restrict__ band_cnt,
+                                                      uint32_t* __restrict__ level_kept,
+                                                      int32_t* __restrict__ level_cutoff)
+{
+    __shared__ uint32_t sh[256];
+    const int b = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int l = find_level_by_band(g, b);
+    const slamfe_dev_level L = g.lv[l];
+    int cut;
+    uint32_t kept;
+    level_cut(hist + ((size_t)f * g.nlevels + l) * 256, L.quota, sh, &cut, &kept);
+    const int bl = b - L.band_base;
+    if (bl == 0 && tid == 0) {
+        level_kept[f * SLAMFE_MAX_LEVELS + l] = kept;
+        level_cutoff[f * SLAMFE_MAX_LEVELS + l] = cut;
+    }
+    size_t t0 = (size_t)f * g.total_tiles + L.tile_base + (size_t)bl * L.tiles_x;
+    int cnt = 0;
+    for (int tx = 0; tx < L.tiles_x; ++tx) {
+        uint32_t n = cand_cnt[t0 + tx];
+        if (tid < n) cnt += (int)SLAMFE_KEY_S(cand[(t0 + tx) * SLAMFE_TILE_CAND + tid]) >= cut;
+    }
+    sh[tid] = (uint32_t)cnt;
+    __syncthreads();
+    for (int ofs = 128; ofs > 0; ofs >>= 1) {
+        if (tid < ofs) sh[tid] += sh[tid + ofs];
+        __syncthreads();
+    }
+    if (tid == 0) band_cnt[(size_t)f * g.total_bands + b] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void k_select_write(
+    slamfe_dev_geom g, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
+    const uint32_t* __restrict__ band_cnt, const uint32_t* __restrict__ level_kept,
+    const int32_t* __restrict__ level_cutoff, int slot_base, int nslots,
+    uint32_t* __restrict__ kp_key, uint32_t* __restrict__ kp_level, int32_t* __restrict__ kp_count,
+    int max_kp)
+{
+    extern __shared__ uint32_t lds[]; // sort buffer: tiles_x_max * 256 entries, power of two
+    __shared__ uint32_t red[256];
+    __shared__ uint32_t nkeep;
+    const int b = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int l = find_level_by_band(g, b);
+    const slamfe_dev_level L = g.lv[l];
+    const int bl = b - L.band_base;
+    const int cut = level_cutoff[f * SLAMFE_MAX_LEVELS + l];
+    const int slot = (slot_base + f) % nslots;
+
+    // offset = kept keypoints of lower levels + kept of earlier bands of this level
+    uint32_t part = 0;
+    if (tid < l) part = level_kept[f * SLAMFE_MAX_LEVELS + tid];
+    for (int i = tid; i < bl; i += 256) part += band_cnt[(size_t)f * g.total_bands + L.band_base + i];
+    red[tid] = part;
+    if (tid == 0) nkeep = 0;
+    __syncthreads();
+    for (int ofs = 128; ofs > 0; ofs >>= 1) {
+        if (tid < ofs) red[tid] += red[tid + ofs];
+        __syncthreads();
+    }
+    const uint32_t offset = red[0];
+    if (b == 0 && tid == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < g.nlevels; ++i) tot += level_kept[f * SLAMFE_MAX_LEVELS + i];
+        kp_count[slot] = (int32_t)tot;
+    }
+
+    size_t t0 = (size_t)f * g.total_tiles + L.tile_base + (size_t)bl * L.tiles_x;
+    for (int tx = 0; tx < L.tiles_x; ++tx) {
+        uint32_t n = cand_cnt[t0 + tx];
+        if (tid < n) {
+            uint32_t k = cand[(t0 + tx) * SLAMFE_TILE_CAND + tid];
+            if ((int)SLAMFE_KEY_S(k) >= cut) lds[atomicAdd(&nkeep, 1u)] = k;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = nkeep;
+    if (n == 0) return;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + tid; i < np2; i += 256) lds[i] = 0xffffffffu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < np2; i += 256) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    uint32_t a = lds[i], c = lds[ixj];
+                    bool asc = (i & k) == 0;
+                    if ((a > c) == asc) {
+                        lds[i] = c;
+                        lds[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < n; i += 256) {
+        uint32_t o = offset + i;
+        if (o < (uint32_t)max_kp) {
+            kp_key[(size_t)slot * max_kp + o] = lds[i];
+            kp_level[(size_t)slot * max_kp + o] = (uint32_t)l;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5  orientation by intensity centroid (ICAngles inside cv::ORB) and the
+//     final cv::KeyPoint record.  One wavefront per keypoint: the 749-pixel
+//     disc is covered two rows at a time by the two 32-lane halves.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
+                                                int slot_base, int nslots,
+                                                const uint32_t* __restrict__ kp_key,
+                                                const uint32_t* __restrict__ kp_level,
+                                                const int32_t* __restrict__ kp_count,
+                                                slamfe_keypoint* __restrict__ kps, int max_kp,
+                                                int mode, int patch_size)
+{
+    const int f = blockIdx.y;
+    const int slot = (slot_base + f) % nslots;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int n = kp_count[slot];
+    if (n > max_kp) n = max_kp;
+    if (idx >= n) return;
+    const uint32_t key = kp_key[(size_t)slot * max_kp + idx];
+    const int l = (int)kp_level[(size_t)slot * max_kp + idx];
+    const slamfe_dev_level L = g.lv[l];
+    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+    float angle = -1.f;
+    if (mode == SLAMFE_MODE_ORB) {
+        const uint8_t* c = pyr + (size_t)f * g.frame_bytes + L.off + (size_t)cy * L.pitch + cx;
+        // half-widths of the disc rows |v| = 0..15, one nibble each
+        const unsigned long long umax = 0x3689abcddeeeffffULL;
+        const int half = lane >> 5, ul = lane & 31, u = ul - 15;
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            int v = -15 + 2 * it + half;
+            int av = v < 0 ? -v : v;
+            int d = av <= 15 ? (int)((umax >> (4 * av)) & 15ULL) : -1;
+            int au = u < 0 ? -u : u;
+            if (ul < 31 && au <= d) {
+                int val = c[v * L.pitch + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+        angle = slamfe_fast_atan2((float)m01, (float)m10);
+    }
+    if (lane == 0) {
+        slamfe_keypoint k;
+        if (mode == SLAMFE_MODE_ORB) {
+            k.x = (float)cx * L.scale;
+            k.y = (float)cy * L.scale;
+            k.size = (float)patch_size * L.scale;
+            k.octave = l;
+        } else {
+            k.x = (float)cx;
+            k.y = (float)cy;
+            k.size = 7.f;
+            k.octave = 0;
+        }
+        k.angle = angle;
+        k.response = (float)SLAMFE_KEY_S(key);
+        k.class_id = -1;
+        kps[(size_t)slot * max_kp + idx] = k;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6  7x7 sigma=2 Gaussian, 8-bit fixed point, BORDER_REFLECT_101
+//     (GaussianBlur(workingMat, ..., Size(7,7), 2, 2) inside cv::ORB)
+// ---------------------------------------------------------------------------
+#define BL_W (TW + 6)
+#define BL_H (TH + 6)
+
+__global__ __launch_bounds__(256) void k_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
+                                              uint8_t* __restrict__ blur)
+{
+    __shared__ uint8_t tile[BL_H * BL_W];
+    __shared__ uint16_t rows[BL_H * TW];
+    constexpr int K[7] = SLAMFE_GAUSS7_INIT;
+    const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int l = find_level_by_tile(g, t);
+    const slamfe_dev_level L = g.lv[l];
+    const int tl = t - L.tile_base;
+    const int x0 = (tl % L.tiles_x) * TW, y0 = (tl / L.tiles_x) * TH;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
+    uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off;
+
+    for (int i = tid; i < BL_H * BL_W; i += 256) {
+        int ly = i / BL_W, lx = i - ly * BL_W;
+        int gy = reflect101(y0 - 3 + ly, L.h), gx = reflect101(x0 - 3 + lx, L.w);
+        tile[i] = img[(size_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < BL_H * TW; i += 256) {
+        int ly = i / TW, lx = i - ly * TW;
+        const uint8_t* p = &tile[ly * BL_W + lx];
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc += K[k] * p[k];
+        rows[i] = (uint16_t)acc; // <= 257 * 255 = 65535
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int py = (tid >> 6) + 4 * r, px = tid & 63;
+        int gx = x0 + px, gy = y0 + py;
+        if (gx < L.w && gy < L.h) {
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) acc += K[k] * (int)rows[(py + k) * TW + px];
+            int v = (acc + (1 << 15)) >> 16;
+            out[(size_t)gy * L.pitch + gx] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K7  rBRIEF-256 (computeOrbDescriptors inside cv::ORB, reached from
+//     desc->compute, Init.cc:78).  One wavefront per keypoint; lane i evaluates
+//     tests i, 64+i, 128+i, 192+i, so each wave ballot is 8 descriptor bytes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8_t* __restrict__ blur,
+                                                  int slot_base, int nslots,
+                                                  const uint32_t* __restrict__ kp_key,
+                                                  const uint32_t* __restrict__ kp_level,
+                                                  const int32_t* __restrict__ kp_count,
+                                                  const slamfe_keypoint* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int max_kp)
+{
+    const int f = blockIdx.y;
+    const int slot = (slot_base + f) % nslots;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int n = kp_count[slot];
+    if (n > max_kp) n = max_kp;
+    if (idx >= n) return;
+    const uint32_t key = kp_key[(size_t)slot * max_kp + idx];
+    const int l = (int)kp_level[(size_t)slot * max_kp + idx];
+    const slamfe_dev_level L = g.lv[l];
+    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+    const float angle = kps[(size_t)slot * max_kp + idx].angle;
+    float a, b; // a = cos, b = sin
+    slamfe_sincos_deg(angle, &b, &a);
+    const uint8_t* c = blur + (size_t)f * g.frame_bytes + L.off + (size_t)cy * L.pitch + cx;
+    unsigned long long word[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int8_t* t = c_pattern + (j * 64 + lane) * 4;
+        float px0 = (float)t[0], py0 = (float)t[1], px1 = (float)t[2], py1 = (float)t[3];
+        float x0 = px0 * a - py0 * b, y0 = px0 * b + py0 * a;
+        float x1 = px1 * a - py1 * b, y1 = px1 * b + py1 * a;
+        int v0 = c[slamfe_round_f(y0) * L.pitch + slamfe_round_f(x0)];
+        int v1 = c[slamfe_round_f(y1) * L.pitch + slamfe_round_f(x1)];
+        word[j] = __ballot(v0 < v1);
+    }
+    if (lane < 4) {
+        unsigned long long w = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+        reinterpret_cast<unsigned long long*>(desc + ((size_t)slot * max_kp + idx) * 32)[lane] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K8  brute-force Hamming k=2 (BFMatcher::knnMatch, Init.cc:131) + ratio test
+//     (Init.cc:146-147).
+//
+// A lane owns QPT query rows in registers (8 dwords each).  Train rows are
+// read through wave-uniform addresses (scalar loads), so one comparison is
+// 8 v_xor + 8 accumulating v_bcnt; the running top-2 is kept as packed keys
+// (distance << 23 | train row), for which integer min *is* the (distance,
+// index) order of knnMatch.  The train set is cut into chunks over gridDim.y;
+// k_match_merge folds the per-chunk top-2.
+// ---------------------------------------------------------------------------
+template <int QPT>
+__global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ query, int nq_imm,
+                                               const int32_t* __restrict__ nq_dev,
+                                               const uint32_t* __restrict__ train, int nt_imm,
+                                               const int32_t* __restrict__ nt_dev, int cap,
+                                               int chunk_rows, uint32_t* __restrict__ part)
+{
+    int nq = nq_dev ? min(*nq_dev, cap) : nq_imm;
+    int nt = nt_dev ? min(*nt_dev, cap) : nt_imm;
+    const int qbase = (blockIdx.x * 256 + threadIdx.x) * QPT;
+    if (blockIdx.x * 256 * QPT >= nq) return;
+    const int j0 = blockIdx.y * chunk_rows;
+    const int j1 = min(nt, j0 + chunk_rows);
+    uint32_t q[QPT][8];
+    uint32_t b1[QPT], b2[QPT];
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        int qi = min(qbase + i, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 8);
+        uint4 lo = p[0], hi = p[1];
+        q[i][0] = lo.x; q[i][1] = lo.y; q[i][2] = lo.z; q[i][3] = lo.w;
+        q[i][4] = hi.x; q[i][5] = hi.y; q[i][6] = hi.z; q[i][7] = hi.w;
+        b1[i] = b2[i] = SLAMFE_MKEY_NONE;
+    }
+    for (int j = j0; j < j1; ++j) {
+        const uint32_t* t = train + (size_t)j * 8; // wave-uniform
+        uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6],
+                 t7 = t[7];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            uint32_t d = __popc(q[i][0] ^ t0);
+            d += __popc(q[i][1] ^ t1);
+            d += __popc(q[i][2] ^ t2);
+            d += __popc(q[i][3] ^ t3);
+            d += __popc(q[i][4] ^ t4);
+            d += __popc(q[i][5] ^ t5);
+            d += __popc(q[i][6] ^ t6);
+            d += __popc(q[i][7] ^ t7);
+            uint32_t key = (d << SLAMFE_MKEY_SHIFT) | (uint32_t)j;
+            uint32_t nb1 = min(key, b1[i]);
+            // new second best = median of (key, b1, b2) because b1 <= b2
+            uint32_t mx = max(key, b1[i]);
+            b2[i] = min(mx, b2[i]);
+            b1[i] = nb1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        int qi = qbase + i;
+        if (qi < nq) {
+            uint2 o = make_uint2(b1[i], b2[i]);
+            reinterpret_cast<uint2*>(part)[(size_t)blockIdx.y * cap + qi] = o;
+        }
+    }
+}
+
+// Fold per-chunk top-2 keys.  Output either match rows (ratio test applied) or
+// 64-bit shard keys (distance << 32 | global train index).
+__global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict__ part, int nchunks,
+                                                     int cap, int nq_imm,
+                                                     const int32_t* __restrict__ nq_dev,
+                                                     const int32_t* __restrict__ nt_dev, int nt_imm,
+                                                     int chunk_rows, float ratio,
+                                                     slamfe_match2* __restrict__ out,
+                                                     uint64_t* __restrict__ out_keys,
+                                                     int64_t train_base)
+{
+    int nq = nq_dev ? min(*nq_dev, cap) : nq_imm;
+    int nt = nt_dev ? min(*nt_dev, cap) : nt_imm;
+    int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int used = (nt + chunk_rows - 1) / chunk_rows;
+    if (used > nchunks) used = nchunks;
+    uint32_t b1 = SLAMFE_MKEY_NONE, b2 = SLAMFE_MKEY_NONE;
+    for (int c = 0; c < used; ++c) {
+        uint2 p = reinterpret_cast<const uint2*>(part)[(size_t)c * cap + qi];
+        uint32_t k = p.x;
+        uint32_t mx = max(k, b1);
+        b1 = min(k, b1);
+        b2 = min(mx, b2);
+        k = p.y;
+        mx = max(k, b1);
+        b1 = min(k, b1);
+        b2 = min(mx, b2);
+    }
+    const uint32_t mask = (1u << SLAMFE_MKEY_SHIFT) - 1u;
+    if (out_keys) {
+        uint64_t k0 = ~0ULL, k1 = ~0ULL;
+        if (b1 != SLAMFE_MKEY_NONE)
+            k0 = ((uint64_t)(b1 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b1 & mask));
+        if (b2 != SLAMFE_MKEY_NONE)
+            k1 = ((uint64_t)(b2 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b2 & mask));
+        out_keys[(size_t)qi * 2] = k0;
+        out_keys[(size_t)qi * 2 + 1] = k1;
+    }
+    if (out) {
+        slamfe_match2 m;
+        m.idx0 = b1 != SLAMFE_MKEY_NONE ? (int32_t)(b1 & mask) : -1;
+        m.idx1 = b2 != SLAMFE_MKEY_NONE ? (int32_t)(b2 & mask) : -1;
+        m.d0 = (uint16_t)(b1 != SLAMFE_MKEY_NONE ? b1 >> SLAMFE_MKEY_SHIFT : 0);
+        m.d1 = (uint16_t)(b2 != SLAMFE_MKEY_NONE ? b2 >> SLAMFE_MKEY_SHIFT : 0);
+        m.nfound = (uint8_t)((m.idx0 >= 0) + (m.idx1 >= 0));
+        m.ratio_pass = (uint8_t)(m.nfound == 2 && (float)m.d0 < ratio * (float)m.d1);
+        m.reserved[0] = m.reserved[1] = 0;
+        out[qi] = m;
+    }
+}
+
+// Merge key sets of several shards ([shard][nq][2], each ascending).
+__global__ __launch_bounds__(256) void k_merge_shard_keys(const uint64_t* __restrict__ keys,
+                                                          int nshards, int nq, float ratio,
+                                                          slamfe_match2* __restrict__ out)
+{
+    int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint64_t b1 = ~0ULL, b2 = ~0ULL;
+    for (int s = 0; s < nshards; ++s)
+        for (int e = 0; e < 2; ++e) {
+            uint64_t k = keys[((size_t)s * nq + qi) * 2 + e];
+            uint64_t mx = k > b1 ? k : b1;
+            b1 = k < b1 ? k : b1;
+            b2 = mx < b2 ? mx : b2;
+        }
+    slamfe_match2 m;
+    m.idx0 = b1 != ~0ULL ? (int32_t)(b1 & 0xffffffffULL) : -1;
+    m.idx1 = b2 != ~0ULL ? (int32_t)(b2 & 0xffffffffULL) : -1;
+    m.d0 = (uint16_t)(b1 != ~0ULL ? b1 >> 32 : 0);
+    m.d1 = (uint16_t)(b2 != ~0ULL ? b2 >> 32 : 0);
+    m.nfound = (uint8_t)((b1 != ~0ULL) + (b2 != ~0ULL));
+    m.ratio_pass = (uint8_t)(m.nfound == 2 && (float)m.d0 < ratio * (float)m.d1);
+    m.reserved[0] = m.reserved[1] = 0;
+    out[qi] = m;
+}
+
+// ---------------------------------------------------------------------------
+// K9  search by projection (Init.cc:229-259).
+//
+// Pass 1 (parallel, one workgroup per inlier): test every visible map point
+// against the inlier's keypoint -- pixel distance gate first (Init.cc:389-391
+// arithmetic: float differences, double squares and sqrt, narrowed to float),
+// then Hamming distance against the device-resident map descriptor row -- and
+// keep the PROJ_K best candidates as keys (hamming << 20 | position), sorted.
+// Pass 2 (one wavefront, in inlier order): take the first candidate not yet
+// consumed; that is exactly the reference's "minimum over the remaining
+// points, then erase".  An inlier whose list overflowed and ran dry is
+// re-scanned against all points by the whole wave.
+// ---------------------------------------------------------------------------
+#define PROJ_K 32
+#define PROJ_LDS 2048
+
+__device__ __forceinline__ bool proj_gate(float ux, float uy, float kx, float ky, float radius)
+{
+    float dx = ux - kx, dy = uy - ky;
+    double dd = (double)dx * (double)dx + (double)dy * (double)dy;
+    float e = (float)sqrt(dd);
+    return e <= radius;
+}
+
+__device__ __forceinline__ int hamming256_dev(const uint32_t* __restrict__ a,
+                                              const uint32_t* __restrict__ b)
+{
+    const uint4* pa = reinterpret_cast<const uint4*>(a);
+    const uint4* pb = reinterpret_cast<const uint4*>(b);
+    uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__global__ __launch_bounds__(256) void k_proj_candidates(
+    const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
+    const int32_t* __restrict__ kp_idx, int n_inl, const float2* __restrict__ uv,
+    const int32_t* __restrict__ point_ids, int R, const uint32_t* __restrict__ map_desc,
+    float radius, int max_hamming, uint32_t* __restrict__ cand_out, int32_t* __restrict__ cand_n)
+{
+    __shared__ uint32_t lds[PROJ_LDS];
+    __shared__ uint32_t cnt;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int idx = kp_idx[i];
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    if (idx >= 0 && idx < nkp) {
+        const float kx = kps[idx].x, ky = kps[idx].y;
+        const uint32_t* qd = fdesc + (size_t)idx * 8;
+        for (int j = tid; j < R; j += 256) {
+            float2 p = uv[j];
+            if (proj_gate(p.x, p.y, kx, ky, radius)) {
+                int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
+                if (h <= max_hamming) {
+                    uint32_t pos = atomicAdd(&cnt, 1u);
+                    if (pos < PROJ_LDS) lds[pos] = ((uint32_t)h << 20) | (uint32_t)j;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = cnt;
+    if (n > PROJ_LDS) { // too dense to rank here: leave it to the serial pass
+        if (tid == 0) cand_n[i] = -1;
+        return;
+    }
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t k = n + tid; k < np2; k += 256) lds[k] = 0xffffffffu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t e = tid; e < np2; e += 256) {
+                uint32_t exj = e ^ j;
+                if (exj > e) {
+                    uint32_t a = lds[e], c = lds[exj];
+                    bool asc = (e & k) == 0;
+                    if ((a > c) == asc) {
+                        lds[e] = c;
+                        lds[exj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid < PROJ_K && tid < n) cand_out[(size_t)i * PROJ_K + tid] = lds[tid];
+    // cand_n: number of stored candidates; bit 30 set if more passed the gates
+    if (tid == 0) cand_n[i] = (int32_t)(n < PROJ_K ? n : (PROJ_K | (n > PROJ_K ? (1 << 30) : 0)));
+}
+
+__global__ __launch_bounds__(64) void k_proj_resolve(
+    const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
+    const int32_t* __restrict__ kp_idx, int n_inl, const float2* __restrict__ uv,
+    const int32_t* __restrict__ point_ids, int R, const uint32_t* __restrict__ map_desc,
+    float radius, int max_hamming, const uint32_t* __restrict__ cand,
+    const int32_t* __restrict__ cand_n, int32_t* __restrict__ matched)
+{
+    extern __shared__ uint32_t taken[]; // one bit per visible point, (R+31)/32 words
+    const int lane = threadIdx.x;
+    for (int w = lane; w < (R + 31) / 32; w += 64) taken[w] = 0;
+    __syncthreads();
+    for (int i = 0; i < n_inl; ++i) {
+        const int cn = cand_n[i];
+        int result = -1; // position j of the chosen point
+        bool rescan = cn < 0;
+        if (!rescan) {
+            const int n = cn & 0xffff;
+            // first stored candidate whose point is still available
+            uint32_t key = 0xffffffffu;
+            bool avail = false;
+            if (lane < n) {
+                key = cand[(size_t)i * PROJ_K + lane];
+                uint32_t j = key & 0xfffffu;
+                avail = !((taken[j >> 5] >> (j & 31)) & 1u);
+            }
+            unsigned long long m = __ballot(avail);
+            if (m) {
+                int first = __ffsll((long long)m) - 1;
+                result = (int)(__shfl(key, first) & 0xfffffu);
+            } else if (cn & (1 << 30)) {
+                rescan = true;
+            }
+        }
+        if (rescan) {
+            const int idx = kp_idx[i];
+            uint32_t best = 0xffffffffu;
+            if (idx >= 0 && idx < nkp) {
+                const float kx = kps[idx].x, ky = kps[idx].y;
+                const uint32_t* qd = fdesc + (size_t)idx * 8;
+                for (int j = lane; j < R; j += 64) {
+                    if ((taken[j >> 5] >> (j & 31)) & 1u) continue;
+                    float2 p = uv[j];
+                    if (!proj_gate(p.x, p.y, kx, ky, radius)) continue;
+                    int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
+                    if (h <= max_hamming) best = min(best, ((uint32_t)h << 20) | (uint32_t)j);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+            if (best != 0xffffffffu) result = (int)(best & 0xfffffu);
+        }
+        if (lane == 0) {
+            matched[i] = result >= 0 ? point_ids[result] : -1;
+            if (result >= 0) taken[result >> 5] |= 1u << (result & 31);
+        }
+        __syncthreads(); // one wave: orders lane 0's LDS update before the next reads
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+#define LAUNCH_CHECK()                          \
+    do {                                        \
+        hipError_t e_ = hipGetLastError();      \
+        if (e_ != hipSuccess) return (int)e_;   \
+    } while (0)
+
+int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int stride,
+                         size_t frame_stride, int channels, int nframes, uint8_t* pyr,
+                         uint32_t frame_bytes, int pitch)
+{
+    dim3 grid((w + 255) / 256, h, nframes);
+    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, d_in, w, h, stride, frame_stride, channels,
+                       pyr, frame_bytes, pitch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
+                          const uint32_t* taps)
+{
+    for (int l = 1; l < g.nlevels; ++l) {
+        dim3 grid((g.lv[l].w + 63) / 64, (g.lv[l].h + 3) / 4, nframes);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, g, l, pyr, taps);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int slamfe_launch_fast(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                       int thr, int edge, uint32_t* cand, uint32_t* cand_cnt, uint32_t* hist)
+{
+    hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, thr, edge, cand,
+                       cand_cnt, hist);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,
+                         const uint32_t* cand_cnt, const uint32_t* hist, uint32_t* band_cnt,
+                         uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
+                         uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
+                         size_t sort_lds_bytes)
+{
+    hipLaunchKernelGGL(k_select_count, dim3(g.total_bands, nframes), dim3(256), 0, s, g, cand,
+                       cand_cnt, hist, band_cnt, level_kept, level_cutoff);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_select_write, dim3(g.total_bands, nframes), dim3(256), sort_lds_bytes, s, g,
+                       cand, cand_cnt, band_cnt, level_kept, level_cutoff, slot_base, nslots, kp_key,
+                       kp_level, kp_count, max_kp);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                         int slot_base, int nslots, const uint32_t* kp_key,
+                         const uint32_t* kp_level, const int32_t* kp_count, slamfe_keypoint* kps,
+                         int max_kp, int mode, int patch_size)
+{
+    hipLaunchKernelGGL(k_orient, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, pyr,
+                       slot_base, nslots, kp_key, kp_level, kp_count, kps, max_kp, mode, patch_size);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                       uint8_t* blur)
+{
+    hipLaunchKernelGGL(k_blur, dim3(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* blur,
+                           int slot_base, int nslots, const uint32_t* kp_key,
+                           const uint32_t* kp_level, const int32_t* kp_count,
+                           const slamfe_keypoint* kps, uint8_t* desc, int max_kp)
+{
+    hipLaunchKernelGGL(k_describe, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, blur,
+                       slot_base, nslots, kp_key, kp_level, kp_count, kps, desc, max_kp);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_match_plan(int nq_max, int nt_max, int* qpt, int* chunk_rows, int* nchunks)
+{
+    // enough workgroups to fill 256 CUs several times over, chunks >= 64 rows
+    int q = nq_max >= 16384 ? 2 : 1;
+    int qblocks = (nq_max + 256 * q - 1) / (256 * q);
+    if (qblocks < 1) qblocks = 1;
+    int want = 2048 / qblocks;
+    if (want < 1) want = 1;
+    int rows = (nt_max + want - 1) / want;
+    if (rows < 64) rows = 64;
+    rows = (rows + 63) / 64 * 64;
+    int nc = (nt_max + rows - 1) / rows;
+    if (nc < 1) nc = 1;
+    *qpt = q;
+    *chunk_rows = rows;
+    *nchunks = nc;
+    return 0;
+}
+
+int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int32_t* d_nq,
+                        const uint8_t* d_train, int nt, const int32_t* d_nt, int cap, int qpt,
+                        int chunk_rows, int nchunks, uint32_t* part, float ratio,
+                        slamfe_match2* d_out, uint64_t* d_keys, int64_t train_base)
+{
+    int nq_grid = d_nq ? cap : nq;
+    if (nq_grid <= 0) return 0;
+    dim3 grid((nq_grid + 256 * qpt - 1) / (256 * qpt), nchunks);
+    const uint32_t* q32 = reinterpret_cast<const uint32_t*>(d_query);
+    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(d_train);
+    if (qpt == 2)
+        hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, cap,
+                           chunk_rows, part);
+    else
+        hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, cap,
+                           chunk_rows, part);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_match_merge, dim3((nq_grid + 255) / 256), dim3(256), 0, s, part, nchunks, cap,
+                       nq, d_nq, d_nt, nt, chunk_rows, ratio, d_out, d_keys, train_base);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int nshards, int nq,
+                                   float ratio, slamfe_match2* d_out)
+{
+    if (nq <= 0) return 0;
+    hipLaunchKernelGGL(k_merge_shard_keys, dim3((nq + 255) / 256), dim3(256), 0, s, d_keys, nshards,
+                       nq, ratio, d_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
+                             const int32_t* kp_idx, int n_inl, const float* uv,
+                             const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
+                             int max_hamming, uint32_t* cand, int32_t* cand_n, int32_t* matched)
+{
+    if (n_inl <= 0) return 0;
+    hipLaunchKernelGGL(k_proj_candidates, dim3(n_inl), dim3(256), 0, s, kps,
+                       reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
+                       reinterpret_cast<const float2*>(uv), point_ids, R,
+                       reinterpret_cast<const uint32_t*>(map_desc), radius, max_hamming, cand, cand_n);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), ((size_t)R + 31) / 32 * 4 + 4, s, kps,
+                       reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
+                       reinterpret_cast<const float2*>(uv), point_ids, R,
+                       reinterpret_cast<const uint32_t*>(map_desc), radius, max_hamming, cand, cand_n,
+                       matched);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// Raise the dynamic-LDS limits of the two kernels that may need more than the
+// default 64 KiB (4K-wide frames; very large local maps).
+int slamfe_kernels_init(size_t sort_lds_bytes)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_write),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sort_lds_bytes > 65536 ? sort_lds_bytes : 65536));
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            SLAMFE_PROJ_MAX_POINTS / 8 + 64);
+    if (e != hipSuccess) return (int)e;
+    return 0;
+}

@@ -1,0 +1,256 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU checker
+on the same seeded inputs.  Bit-exact everywhere (integer / byte / index work;
+the two float routines are shared source with -ffp-contract=off).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe_orb():
+    from slam_amd.frontend import FrontEnd
+    fe = FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=2000, max_width=1280,
+                  max_height=720, max_batch=4, map_capacity=1 << 15)
+    yield fe
+    fe.close()
+
+
+@pytest.fixture(scope="module")
+def fe_ref():
+    from slam_amd.frontend import FrontEnd
+    fe = FrontEnd(mode=abi.MODE_PROVIDED, fast_threshold=30, max_width=1280, max_height=720,
+                  max_batch=2)
+    yield fe
+    fe.close()
+
+
+def oracle_params(fe):
+    p = abi.Params()
+    for name, _ in abi.Params._fields_:
+        setattr(p, name, getattr(fe.params, name))
+    return p
+
+
+def assert_frame_equal(frame, kps, desc):
+    assert len(frame) == len(kps), (len(frame), len(kps))
+    for name in abi.KEYPOINT_DTYPE.names:
+        bad = np.nonzero(frame.keypoints[name] != kps[name])[0]
+        assert len(bad) == 0, (name, bad[:5], frame.keypoints[bad[:5]], kps[bad[:5]])
+    bad = np.nonzero((frame.descriptors != desc).any(axis=1))[0]
+    assert len(bad) == 0, (bad[:5], len(bad))
+
+
+# ------------------------------------------------------------ stage parity
+def test_pyramid_and_blur_levels(fe_orb):
+    img, _ = synth.frame_pair(640, 480)
+    fe_orb.extract_keypoints(img)
+    levels = O.build_pyramid(img)
+    for l, want in enumerate(levels):
+        got = fe_orb.debug_read_level(0, l, False)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), f"pyramid level {l}"
+        assert np.array_equal(fe_orb.debug_read_level(0, l, True), O.blur7(want)), f"blur {l}"
+
+
+@pytest.mark.parametrize("shape", [(333, 277), (200, 160), (97, 131)])
+def test_pyramid_ragged_sizes(fe_orb, shape):
+    w, h = shape
+    img = synth.textured_canvas(w, h, 41)
+    fe_orb.extract_keypoints(img)
+    for l, want in enumerate(O.build_pyramid(img)):
+        assert np.array_equal(fe_orb.debug_read_level(0, l, False), want)
+        assert np.array_equal(fe_orb.debug_read_level(0, l, True), O.blur7(want))
+
+
+# --------------------------------------------------------------- extraction
+def test_extract_orb_640x480_pair(fe_orb):
+    a, b = synth.frame_pair(640, 480)
+    p = oracle_params(fe_orb)
+    for img in (a, b):
+        f = fe_orb.extract_keypoints(img)
+        kps, desc = O.extract(p, img)
+        assert len(kps) >= 2000
+        assert_frame_equal(f, kps, desc)
+        ang = np.radians(f.keypoints["angle"].astype(np.float64) - kps["angle"])
+        assert np.abs(ang).max() <= 1e-3  # the stated orientation tolerance (here: exact)
+
+
+@pytest.mark.parametrize("shape,seed", [((333, 277), 42), ((200, 160), 43), ((1241, 376), 44),
+                                        ((1280, 720), 45), ((70, 70), 46), ((64, 64), 47)])
+def test_extract_orb_other_sizes(fe_orb, shape, seed):
+    w, h = shape
+    img = synth.textured_canvas(w, h, seed)
+    f = fe_orb.extract_keypoints(img)
+    kps, desc = O.extract(oracle_params(fe_orb), img)
+    assert_frame_equal(f, kps, desc)
+
+
+def test_extract_flat_image_has_no_keypoints(fe_orb, fe_ref):
+    img = np.full((240, 320), 99, np.uint8)
+    assert len(fe_orb.extract_keypoints(img)) == 0
+    assert len(fe_ref.extract_keypoints(img)) == 0
+
+
+def test_extract_reference_mode(fe_ref):
+    p = oracle_params(fe_ref)
+    for (w, h), seed in (((640, 480), 1), ((1241, 376), 2), ((333, 277), 3)):
+        img = synth.textured_canvas(w, h, seed)
+        f = fe_ref.extract_keypoints(img)
+        kps, desc = O.extract(p, img)
+        assert len(kps) > 100
+        assert_frame_equal(f, kps, desc)
+        assert np.all(f.keypoints["angle"] == -1) and np.all(f.keypoints["size"] == 7)
+        key = f.keypoints["y"].astype(np.int64) * 10000 + f.keypoints["x"].astype(np.int64)
+        assert np.all(np.diff(key) > 0)  # FAST's row-major order
+
+
+def test_extract_bgr_input(fe_orb, fe_ref):
+    g = synth.textured_canvas(320, 240, 48)
+    bgr = np.stack([np.roll(g, 1, 0), g, np.roll(g, 2, 1)], axis=2)
+    for fe in (fe_orb, fe_ref):
+        f = fe.extract_keypoints(bgr)
+        kps, desc = O.extract(oracle_params(fe), bgr)
+        assert len(kps) > 20
+        assert_frame_equal(f, kps, desc)
+
+
+def test_extract_batch_equals_single_frames(fe_orb):
+    frames = synth.frame_stream(640, 480, 4, seed=5)
+    batch = fe_orb.extract_batch(list(frames))
+    p = oracle_params(fe_orb)
+    for img, f in zip(frames, batch):
+        kps, desc = O.extract(p, img)
+        assert_frame_equal(f, kps, desc)
+    again = fe_orb.frame_download(batch[2].handle)
+    assert_frame_equal(again, batch[2].keypoints, batch[2].descriptors)
+
+
+def test_extract_capacity_error():
+    from slam_amd.frontend import FrontEnd, SlamfeError
+    img, _ = synth.frame_pair(640, 480)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=2000, max_keypoints=500,
+                  max_width=640, max_height=480) as fe:
+        with pytest.raises(SlamfeError) as e:
+            fe.extract_keypoints(img)
+        assert e.value.code == abi.SLAMFE_E_CAPACITY
+
+
+def test_frame_handle_expires(fe_orb):
+    from slam_amd.frontend import SlamfeError
+    img = synth.textured_canvas(200, 160, 49)
+    first = fe_orb.extract_keypoints(img)
+    for _ in range(fe_orb.params.frame_slots if fe_orb.params.frame_slots else 8):
+        fe_orb.extract_keypoints(img)
+    with pytest.raises(SlamfeError) as e:
+        fe_orb.frame_download(first.handle)
+    assert e.value.code == abi.SLAMFE_E_HANDLE
+
+
+# ------------------------------------------------------------------ matching
+@pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (1, 2), (257, 63), (64, 1000), (5, 0),
+                                   (3001, 2999), (100, 20000)])
+def test_match_knn2(fe_orb, nq, nt):
+    q, t = synth.descriptor_sets(nq, max(nt, 1), seed=3 + nq, dup_percent=3)
+    t = t[:nt]
+    got = fe_orb.knn_match(q, t)
+    want = O.match_knn2(q, t)
+    for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+        assert np.array_equal(got[name], want[name]), name
+    if nt >= 1000:
+        assert (got["d0"] == got["d1"]).sum() > 0  # ties were exercised
+
+
+def test_match_empty_query(fe_orb):
+    assert len(fe_orb.knn_match(np.zeros((0, 32), np.uint8), np.zeros((4, 32), np.uint8))) == 0
+
+
+def test_match_resident_frames(fe_orb):
+    a, b = synth.frame_pair(640, 480)
+    fa, fb = fe_orb.extract_batch([a, b])
+    got = fe_orb.knn_match_frames(fa, fb)
+    want = O.match_knn2(fa.descriptors, fb.descriptors)
+    assert len(got) == len(fa)
+    for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+        assert np.array_equal(got[name], want[name]), name
+    good = got[got["ratio_pass"] == 1]
+    assert len(good) > 300
+    dx = fb.keypoints["x"][good["idx0"]] - fa.keypoints["x"][got["ratio_pass"] == 1]
+    assert abs(np.median(dx) - 7) < 1.0  # the known (+7, +3) motion
+
+
+def test_match_sharded_keys_merge_equals_single(fe_orb):
+    import torch
+    nq, nt, shards = 300, 5000, 4
+    q, t = synth.descriptor_sets(nq, nt, seed=9, dup_percent=2)
+    dq = torch.from_numpy(q).cuda()
+    dt = torch.from_numpy(t).cuda()
+    keys = torch.empty((shards, nq, 2), dtype=torch.int64, device="cuda")
+    bounds = [0, 1000, 1001, 3500, nt]  # uneven shards, one with a single row
+    torch.cuda.synchronize()
+    for s in range(shards):
+        lo, hi = bounds[s], bounds[s + 1]
+        fe_orb.match_shard_keys(dq.data_ptr(), nq, dt[lo:hi].data_ptr(), hi - lo, lo,
+                                keys[s].data_ptr())
+    out = torch.zeros(nq * 16, dtype=torch.uint8, device="cuda")
+    fe_orb.merge_shard_keys(keys.data_ptr(), shards, nq, out.data_ptr())
+    fe_orb.sync()
+    got = out.cpu().numpy().view(abi.MATCH2_DTYPE)
+    want = O.match_knn2(q, t)
+    for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+        assert np.array_equal(got[name], want[name]), name
+
+
+# ------------------------------------------------------ search by projection
+def test_search_by_projection(fe_orb):
+    img = synth.textured_canvas(1241, 376, 50)
+    f = fe_orb.extract_keypoints(img)
+    npts = 20000
+    uv, pdesc = synth.local_map(f.descriptors, f.pt, npts, 1241, 376, seed=7)
+    ids = np.arange(npts, dtype=np.int32)
+    fe_orb.map_put(ids, pdesc)
+    # visible subset, ascending, like rPointsIdx
+    vis = np.nonzero(synth.rand_below(8, 1, np.arange(npts), 10) < 8)[0].astype(np.int32)
+    inl = synth.rand_below(8, 2, np.arange(1500), len(f)).astype(np.int32)
+    got = fe_orb.search_by_projection(f, inl, uv[vis], vis)
+    want = O.search_by_projection(f.pt, f.descriptors, inl, uv[vis], pdesc[vis], vis)
+    assert np.array_equal(got, want)
+    assert (got >= 0).sum() > 200
+    hit = got[got >= 0]
+    assert len(np.unique(hit)) == len(hit)
+
+
+def test_search_by_projection_dense_cluster(fe_orb):
+    # more candidates per keypoint than the per-inlier list holds, and far more
+    # inliers than points: exercises list overflow, rescans and exhaustion
+    img = synth.textured_canvas(320, 240, 51)
+    f = fe_orb.extract_keypoints(img)
+    assert len(f) > 50
+    k0 = 10
+    n = 3000
+    uv = np.tile(f.pt[k0], (n, 1)).astype(np.float32)
+    uv += (synth.rand_below(9, 1, np.arange(2 * n), 41).reshape(n, 2) - 20).astype(np.float32)
+    pdesc = np.tile(f.descriptors[k0], (n, 1))
+    flips = synth.rand_below(9, 2, np.arange(n), 32)
+    for i in range(n):
+        pdesc[i, flips[i]] ^= 1 + (i % 7)
+    ids = np.arange(100, 100 + n, dtype=np.int32)
+    fe_orb.map_put(ids, pdesc)
+    inl = np.full(200, k0, np.int32)
+    inl[::3] = 11
+    got = fe_orb.search_by_projection(f, inl, uv, ids)
+    want = O.search_by_projection(f.pt, f.descriptors, inl, uv, pdesc, ids)
+    assert np.array_equal(got, want)
+    assert (got >= 0).sum() >= 100
+
+
+def test_search_by_projection_no_points(fe_orb):
+    img = synth.textured_canvas(200, 160, 52)
+    f = fe_orb.extract_keypoints(img)
+    got = fe_orb.search_by_projection(f, [0, 1, 2], np.zeros((0, 2), np.float32),
+                                      np.zeros(0, np.int32))
+    assert list(got) == [-1, -1, -1]
