@@ -150,6 +150,13 @@ int slamfe_match_frames(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_fr
 int slamfe_match_resident(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
                           slamfe_match2* d_out);
 
+/* Batched asynchronous form: pair i matches frame first_query + i against
+ * frame first_train + i (handles of consecutive extractions are consecutive),
+ * writing rows to d_out + i * max_keypoints.  One launch for all pairs: this
+ * is the per-frame loop of Init.cc:130-131 for a pipelined batch. */
+int slamfe_match_resident_batch(slamfe_ctx* ctx, uint64_t first_query, uint64_t first_train,
+                                int npairs, slamfe_match2* d_out);
+
 /* Sharded brute-force matching (relocalisation against a map split over
  * several GPUs).  d_query: nq x 32 B, d_train: this shard's nt x 32 B whose
  * first row has global index train_base.  Writes, per query, the shard's two
@@ -193,6 +200,20 @@ int slamfe_sync(slamfe_ctx* ctx);
  * device-side count. */
 int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamfe_keypoint** d_kps,
                              const uint8_t** d_desc, const int32_t** d_count);
+
+/* Measurement hook (no counterpart in the reference): re-run one stage of the
+ * most recent extraction of `nframes` frames `reps` times on the context's
+ * stream, bracketed by HIP events on that stream, and return the average
+ * milliseconds per repetition.  Every stage is idempotent on the resident
+ * data, so the frame results are unchanged afterwards. */
+#define SLAMFE_STAGE_PYRAMID 1
+#define SLAMFE_STAGE_FAST 2
+#define SLAMFE_STAGE_SELECT 3
+#define SLAMFE_STAGE_ORIENT 4
+#define SLAMFE_STAGE_BLUR 5
+#define SLAMFE_STAGE_DESCRIBE 6
+#define SLAMFE_STAGE_MATCH 7
+int slamfe_debug_time_stage(slamfe_ctx* ctx, int stage, int nframes, int reps, float* avg_ms);
 
 /* Test hook (no counterpart in the reference): copy pyramid level `level` of
  * frame `frame_in_batch` of the most recent extraction to the host, either

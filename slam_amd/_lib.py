@@ -34,6 +34,8 @@ SIGNATURES = {
     "slamfe_match_knn2": (C.c_int, [ctxp, vp, C.c_int, vp, C.c_int, vp]),
     "slamfe_match_frames": (C.c_int, [ctxp, C.c_uint64, C.c_uint64, vp, C.c_int, i32p]),
     "slamfe_match_resident": (C.c_int, [ctxp, C.c_uint64, C.c_uint64, vp]),
+    "slamfe_match_resident_batch": (C.c_int, [ctxp, C.c_uint64, C.c_uint64, C.c_int, vp]),
+    "slamfe_debug_time_stage": (C.c_int, [ctxp, C.c_int, C.c_int, C.c_int, f32p]),
     "slamfe_match_shard_keys": (C.c_int, [ctxp, vp, C.c_int, vp, C.c_int, C.c_int64, vp]),
     "slamfe_merge_shard_keys": (C.c_int, [ctxp, vp, C.c_int, C.c_int, vp]),
     "slamfe_map_put": (C.c_int, [ctxp, vp, vp, C.c_int]),

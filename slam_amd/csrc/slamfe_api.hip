@@ -541,7 +541,7 @@ int slamfe_match_knn2(slamfe_ctx* c, const uint8_t* query, int nq, const uint8_t
     KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)c->match_q.p, nq, nullptr,
                                 (const uint8_t*)c->match_t.p, nt, nullptr, nq, qpt, chunk, nchunks,
                                 (uint32_t*)c->match_part.p, c->p.ratio, (slamfe_match2*)c->match_o.p,
-                                nullptr, 0));
+                                nullptr, 0, 1, 0, 0, 0));
     HIPCHK(c, hipMemcpyAsync(out, c->match_o.p, (size_t)nq * sizeof(slamfe_match2),
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -557,7 +557,24 @@ int slamfe_match_resident(slamfe_ctx* c, uint64_t query_frame, uint64_t train_fr
     KCHK(c, slamfe_launch_match(c->stream, c->desc + (size_t)sq * c->max_kp * 32, 0, c->kp_count + sq,
                                 c->desc + (size_t)st * c->max_kp * 32, 0, c->kp_count + st, c->max_kp,
                                 c->fm_qpt, c->fm_chunk, c->fm_nchunks, (uint32_t*)c->match_part.p,
-                                c->p.ratio, d_out, nullptr, 0));
+                                c->p.ratio, d_out, nullptr, 0, 1, 0, 0, 0));
+    return SLAMFE_OK;
+}
+
+int slamfe_match_resident_batch(slamfe_ctx* c, uint64_t first_query, uint64_t first_train, int npairs,
+                                slamfe_match2* d_out)
+{
+    if (!c || !d_out || npairs < 1 || npairs > c->nslots) return SLAMFE_E_INVALID;
+    for (int i = 0; i < npairs; ++i)
+        if (slot_of(c, first_query + (uint64_t)i) < 0 || slot_of(c, first_train + (uint64_t)i) < 0)
+            return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown (pair %d)", i);
+    int rc = grow(c, c->match_part, (size_t)npairs * c->fm_nchunks * c->max_kp * 8);
+    if (rc) return rc;
+    KCHK(c, slamfe_launch_match(c->stream, c->desc, 0, c->kp_count, c->desc, 0, c->kp_count, c->max_kp,
+                                c->fm_qpt, c->fm_chunk, c->fm_nchunks, (uint32_t*)c->match_part.p,
+                                c->p.ratio, d_out, nullptr, 0, npairs,
+                                (int)(first_query % (uint64_t)c->nslots),
+                                (int)(first_train % (uint64_t)c->nslots), c->nslots));
     return SLAMFE_OK;
 }
 
@@ -600,7 +617,8 @@ int slamfe_match_shard_keys(slamfe_ctx* c, const void* d_query, int nq, const vo
     if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
     KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)d_query, nq, nullptr,
                                 (const uint8_t*)d_train, nt, nullptr, nq, qpt, chunk, nchunks,
-                                (uint32_t*)c->match_part.p, c->p.ratio, nullptr, d_keys, train_base));
+                                (uint32_t*)c->match_part.p, c->p.ratio, nullptr, d_keys, train_base, 1,
+                                0, 0, 0));
     return SLAMFE_OK;
 }
 
@@ -683,6 +701,77 @@ int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp
     HIPCHK(c, hipMemcpyAsync(matched_point_id, c->pj_matched.p, (size_t)n_inl * 4,
                              hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    return SLAMFE_OK;
+}
+
+int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, float* avg_ms)
+{
+    if (!c || !avg_ms || reps < 1 || c->gw == 0 || nframes < 1 || nframes > c->p.max_batch)
+        return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    const slamfe_dev_geom& g = c->geom;
+    hipStream_t s = c->stream;
+    // the slots of the most recent extraction of nframes frames
+    int slot_base = (int)((c->next_seq - (uint64_t)nframes) % (uint64_t)c->nslots);
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) {
+        switch (stage) {
+        case SLAMFE_STAGE_PYRAMID:
+            KCHK(c, slamfe_launch_pyramid(s, g, nframes, c->pyr, c->taps));
+            break;
+        case SLAMFE_STAGE_FAST:
+            // the histograms are zeroed before every FAST pass, as in the real pipeline
+            HIPCHK(c, hipMemsetAsync(c->hist, 0, (size_t)nframes * g.nlevels * 256 * sizeof(uint32_t), s));
+            KCHK(c, slamfe_launch_fast(s, g, nframes, c->pyr, c->p.fast_threshold,
+                                       c->p.edge_threshold, c->cand, c->cand_cnt, c->hist));
+            break;
+        case SLAMFE_STAGE_SELECT:
+            KCHK(c, slamfe_launch_select(s, g, nframes, c->cand, c->cand_cnt, c->hist, c->band_cnt,
+                                         c->level_kept, c->level_cutoff, slot_base, c->nslots,
+                                         c->kp_key, c->kp_level, c->kp_count, c->max_kp, c->sort_lds));
+            break;
+        case SLAMFE_STAGE_ORIENT:
+            KCHK(c, slamfe_launch_orient(s, g, nframes, c->pyr, slot_base, c->nslots, c->kp_key,
+                                         c->kp_level, c->kp_count, c->kps, c->max_kp, c->p.mode,
+                                         c->p.patch_size));
+            break;
+        case SLAMFE_STAGE_BLUR:
+            KCHK(c, slamfe_launch_blur(s, g, nframes, c->pyr, c->blur));
+            break;
+        case SLAMFE_STAGE_DESCRIBE:
+            KCHK(c, slamfe_launch_describe(s, g, nframes, c->blur, slot_base, c->nslots, c->kp_key,
+                                           c->kp_level, c->kp_count, c->kps, c->desc, c->max_kp));
+            break;
+        case SLAMFE_STAGE_MATCH: {
+            int rc = grow(c, c->match_part, (size_t)nframes * c->fm_nchunks * c->max_kp * 8);
+            if (rc) return rc;
+            rc = grow(c, c->match_o, (size_t)nframes * c->max_kp * sizeof(slamfe_match2));
+            if (rc) return rc;
+            // frame i against frame i+1 (the last one against itself)
+            KCHK(c, slamfe_launch_match(s, c->desc, 0, c->kp_count, c->desc, 0, c->kp_count, c->max_kp,
+                                        c->fm_qpt, c->fm_chunk, c->fm_nchunks,
+                                        (uint32_t*)c->match_part.p, c->p.ratio,
+                                        (slamfe_match2*)c->match_o.p, nullptr, 0,
+                                        nframes > 1 ? nframes - 1 : 1, slot_base,
+                                        nframes > 1 ? slot_base + 1 : slot_base, c->nslots));
+            break;
+        }
+        default:
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return fail(c, SLAMFE_E_INVALID, "unknown stage %d", stage);
+        }
+    }
+    HIPCHK(c, hipEventRecord(e1, s));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)reps;
     return SLAMFE_OK;
 }
 

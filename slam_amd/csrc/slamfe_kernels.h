@@ -38,7 +38,8 @@ int slamfe_match_plan(int nq_max, int nt_max, int* qpt, int* chunk_rows, int* nc
 int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int32_t* d_nq,
                         const uint8_t* d_train, int nt, const int32_t* d_nt, int cap, int qpt,
                         int chunk_rows, int nchunks, uint32_t* part, float ratio,
-                        slamfe_match2* d_out, uint64_t* d_keys, int64_t train_base);
+                        slamfe_match2* d_out, uint64_t* d_keys, int64_t train_base, int npairs,
+                        int q_slot_base, int t_slot_base, int nslots);
 int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int nshards, int nq,
                                    float ratio, slamfe_match2* d_out);
 

@@ -379,8 +379,10 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
     if (idx >= n) return;
     const uint32_t key = kp_key[(size_t)slot * max_kp + idx];
     const int l = (int)kp_level[(size_t)slot * max_kp + idx];
+    if (l < 0 || l >= g.nlevels) return; // never true for entries written by k_select_write
     const slamfe_dev_level L = g.lv[l];
     const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+    if (cx < 16 || cy < 16 || cx >= L.w - 16 || cy >= L.h - 16) return; // patch must be inside
     float angle = -1.f;
     if (mode == SLAMFE_MODE_ORB) {
         const uint8_t* c = pyr + (size_t)f * g.frame_bytes + L.off + (size_t)cy * L.pitch + cx;
@@ -499,8 +501,10 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
     if (idx >= n) return;
     const uint32_t key = kp_key[(size_t)slot * max_kp + idx];
     const int l = (int)kp_level[(size_t)slot * max_kp + idx];
+    if (l < 0 || l >= g.nlevels) return; // never true for entries written by k_select_write
     const slamfe_dev_level L = g.lv[l];
     const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+    if (cx < 19 || cy < 19 || cx >= L.w - 19 || cy >= L.h - 19) return; // samples reach 18.4 px
     const float angle = kps[(size_t)slot * max_kp + idx].angle;
     float a, b; // a = cos, b = sin
     slamfe_sincos_deg(angle, &b, &a);
@@ -533,13 +537,30 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
 // index) order of knnMatch.  The train set is cut into chunks over gridDim.y;
 // k_match_merge folds the per-chunk top-2.
 // ---------------------------------------------------------------------------
+// Frame-slot addressing for batched frame-vs-frame matching: pair z (blockIdx.z)
+// matches slot (q_base + z) % nslots against slot (t_base + z) % nslots; rows
+// and counts of slot s are at desc + s * cap * 32 and count + s.  nslots = 0
+// means "plain pointers, one pair".
+struct slamfe_pair_slots {
+    int q_base, t_base, nslots;
+};
+
 template <int QPT>
 __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ query, int nq_imm,
                                                const int32_t* __restrict__ nq_dev,
                                                const uint32_t* __restrict__ train, int nt_imm,
                                                const int32_t* __restrict__ nt_dev, int cap,
-                                               int chunk_rows, uint32_t* __restrict__ part)
+                                               int chunk_rows, uint32_t* __restrict__ part,
+                                               slamfe_pair_slots ps, int nchunks)
 {
+    if (ps.nslots) {
+        int sq = (ps.q_base + (int)blockIdx.z) % ps.nslots, st = (ps.t_base + (int)blockIdx.z) % ps.nslots;
+        query += (size_t)sq * cap * 8;
+        train += (size_t)st * cap * 8;
+        nq_dev += sq;
+        nt_dev += st;
+        part += (size_t)blockIdx.z * nchunks * cap * 2;
+    }
     int nq = nq_dev ? min(*nq_dev, cap) : nq_imm;
     int nt = nt_dev ? min(*nt_dev, cap) : nt_imm;
     const int qbase = (blockIdx.x * 256 + threadIdx.x) * QPT;
@@ -598,8 +619,15 @@ __global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict_
                                                      int chunk_rows, float ratio,
                                                      slamfe_match2* __restrict__ out,
                                                      uint64_t* __restrict__ out_keys,
-                                                     int64_t train_base)
+                                                     int64_t train_base, slamfe_pair_slots ps)
 {
+    if (ps.nslots) {
+        int sq = (ps.q_base + (int)blockIdx.z) % ps.nslots, st = (ps.t_base + (int)blockIdx.z) % ps.nslots;
+        nq_dev += sq;
+        nt_dev += st;
+        part += (size_t)blockIdx.z * nchunks * cap * 2;
+        out += (size_t)blockIdx.z * cap;
+    }
     int nq = nq_dev ? min(*nq_dev, cap) : nq_imm;
     int nt = nt_dev ? min(*nt_dev, cap) : nt_imm;
     int qi = blockIdx.x * 256 + threadIdx.x;
@@ -924,22 +952,25 @@ int slamfe_match_plan(int nq_max, int nt_max, int* qpt, int* chunk_rows, int* nc
 int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int32_t* d_nq,
                         const uint8_t* d_train, int nt, const int32_t* d_nt, int cap, int qpt,
                         int chunk_rows, int nchunks, uint32_t* part, float ratio,
-                        slamfe_match2* d_out, uint64_t* d_keys, int64_t train_base)
+                        slamfe_match2* d_out, uint64_t* d_keys, int64_t train_base, int npairs,
+                        int q_slot_base, int t_slot_base, int nslots)
 {
     int nq_grid = d_nq ? cap : nq;
-    if (nq_grid <= 0) return 0;
-    dim3 grid((nq_grid + 256 * qpt - 1) / (256 * qpt), nchunks);
+    if (nq_grid <= 0 || npairs <= 0) return 0;
+    slamfe_pair_slots ps = {q_slot_base, t_slot_base, nslots};
+    dim3 grid((nq_grid + 256 * qpt - 1) / (256 * qpt), nchunks, npairs);
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(d_query);
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(d_train);
     if (qpt == 2)
         hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, cap,
-                           chunk_rows, part);
+                           chunk_rows, part, ps, nchunks);
     else
         hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, cap,
-                           chunk_rows, part);
+                           chunk_rows, part, ps, nchunks);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_match_merge, dim3((nq_grid + 255) / 256), dim3(256), 0, s, part, nchunks, cap,
-                       nq, d_nq, d_nt, nt, chunk_rows, ratio, d_out, d_keys, train_base);
+    hipLaunchKernelGGL(k_match_merge, dim3((nq_grid + 255) / 256, 1, npairs), dim3(256), 0, s, part,
+                       nchunks, cap, nq, d_nq, d_nt, nt, chunk_rows, ratio, d_out, d_keys, train_base,
+                       ps);
     LAUNCH_CHECK();
     return 0;
 }

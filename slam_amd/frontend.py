@@ -179,6 +179,19 @@ class FrontEnd:
                                                     C.c_uint64(int(train_handle)),
                                                     C.c_void_p(d_out)))
 
+    def match_resident_batch(self, first_query, first_train, npairs: int, d_out: int):
+        self._check(self._lib.slamfe_match_resident_batch(
+            self._ctx, C.c_uint64(int(first_query)), C.c_uint64(int(first_train)), npairs,
+            C.c_void_p(d_out)))
+
+    def time_stage(self, stage: int, nframes: int, reps: int) -> float:
+        """Measurement hook: average milliseconds of one stage, HIP events on
+        the context's stream."""
+        ms = C.c_float()
+        self._check(self._lib.slamfe_debug_time_stage(self._ctx, stage, nframes, reps,
+                                                      C.byref(ms)))
+        return ms.value
+
     def match_shard_keys(self, d_query: int, nq: int, d_train: int, nt: int, train_base: int,
                          d_keys: int):
         self._check(self._lib.slamfe_match_shard_keys(self._ctx, C.c_void_p(d_query), nq,

@@ -254,3 +254,20 @@ def test_search_by_projection_no_points(fe_orb):
     got = fe_orb.search_by_projection(f, [0, 1, 2], np.zeros((0, 2), np.float32),
                                       np.zeros(0, np.int32))
     assert list(got) == [-1, -1, -1]
+
+
+def test_match_resident_batch(fe_orb):
+    import torch
+    frames = synth.frame_stream(640, 480, 4, seed=6)
+    fs = fe_orb.extract_batch(list(frames))
+    cap = fe_orb.max_keypoints
+    out = torch.zeros((3, cap, 16), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    fe_orb.match_resident_batch(fs[0].handle, fs[1].handle, 3, out.data_ptr())
+    fe_orb.sync()
+    got = out.cpu().numpy()
+    for i in range(3):
+        want = O.match_knn2(fs[i].descriptors, fs[i + 1].descriptors)
+        g = got[i].reshape(-1).view(abi.MATCH2_DTYPE)[:len(want)]
+        for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+            assert np.array_equal(g[name], want[name]), (i, name)
