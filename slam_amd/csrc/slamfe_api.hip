@@ -423,7 +423,7 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     HIPCHK(c, hipMalloc(&c->desc, S * K * 32));
     HIPCHK(c, hipMemset(c->kp_count, 0, S * sizeof(int32_t)));
     HIPCHK(c, hipMalloc(&c->match_out, K * sizeof(slamfe_match2)));
-    slamfe_match_plan(c->max_kp, c->max_kp, &c->fm_qpt, &c->fm_chunk, &c->fm_nchunks);
+    slamfe_match_plan(c->max_kp, c->max_kp, 1, &c->fm_qpt, &c->fm_chunk, &c->fm_nchunks);
     int rc = grow(c, c->match_part, (size_t)c->fm_nchunks * K * 8);
     if (rc) return rc;
     if (p.map_capacity > 0) {
@@ -532,7 +532,7 @@ int slamfe_match_knn2(slamfe_ctx* c, const uint8_t* query, int nq, const uint8_t
     if ((rc = grow(c, c->match_t, (size_t)(nt > 0 ? nt : 1) * 32))) return rc;
     if ((rc = grow(c, c->match_o, (size_t)nq * sizeof(slamfe_match2)))) return rc;
     int qpt, chunk, nchunks;
-    slamfe_match_plan(nq, nt, &qpt, &chunk, &nchunks);
+    slamfe_match_plan(nq, nt, 1, &qpt, &chunk, &nchunks);
     if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->match_q.p, query, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
     if (nt > 0)
@@ -568,10 +568,12 @@ int slamfe_match_resident_batch(slamfe_ctx* c, uint64_t first_query, uint64_t fi
     for (int i = 0; i < npairs; ++i)
         if (slot_of(c, first_query + (uint64_t)i) < 0 || slot_of(c, first_train + (uint64_t)i) < 0)
             return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown (pair %d)", i);
-    int rc = grow(c, c->match_part, (size_t)npairs * c->fm_nchunks * c->max_kp * 8);
+    int qpt, chunk, nchunks;
+    slamfe_match_plan(c->max_kp, c->max_kp, npairs, &qpt, &chunk, &nchunks);
+    int rc = grow(c, c->match_part, (size_t)npairs * nchunks * c->max_kp * 8);
     if (rc) return rc;
     KCHK(c, slamfe_launch_match(c->stream, c->desc, 0, c->kp_count, c->desc, 0, c->kp_count, c->max_kp,
-                                c->fm_qpt, c->fm_chunk, c->fm_nchunks, (uint32_t*)c->match_part.p,
+                                qpt, chunk, nchunks, (uint32_t*)c->match_part.p,
                                 c->p.ratio, d_out, nullptr, 0, npairs,
                                 (int)(first_query % (uint64_t)c->nslots),
                                 (int)(first_train % (uint64_t)c->nslots), c->nslots));
@@ -613,7 +615,7 @@ int slamfe_match_shard_keys(slamfe_ctx* c, const void* d_query, int nq, const vo
                     SLAMFE_MAX_TRAIN - 1);
     if (nq == 0) return SLAMFE_OK;
     int qpt, chunk, nchunks, rc;
-    slamfe_match_plan(nq, nt, &qpt, &chunk, &nchunks);
+    slamfe_match_plan(nq, nt, 1, &qpt, &chunk, &nchunks);
     if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
     KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)d_query, nq, nullptr,
                                 (const uint8_t*)d_train, nt, nullptr, nq, qpt, chunk, nchunks,
@@ -746,16 +748,17 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
                                            c->kp_level, c->kp_count, c->kps, c->desc, c->max_kp));
             break;
         case SLAMFE_STAGE_MATCH: {
-            int rc = grow(c, c->match_part, (size_t)nframes * c->fm_nchunks * c->max_kp * 8);
+            int np = nframes > 1 ? nframes - 1 : 1, qpt, chunk, nchunks;
+            slamfe_match_plan(c->max_kp, c->max_kp, np, &qpt, &chunk, &nchunks);
+            int rc = grow(c, c->match_part, (size_t)np * nchunks * c->max_kp * 8);
             if (rc) return rc;
             rc = grow(c, c->match_o, (size_t)nframes * c->max_kp * sizeof(slamfe_match2));
             if (rc) return rc;
             // frame i against frame i+1 (the last one against itself)
             KCHK(c, slamfe_launch_match(s, c->desc, 0, c->kp_count, c->desc, 0, c->kp_count, c->max_kp,
-                                        c->fm_qpt, c->fm_chunk, c->fm_nchunks,
+                                        qpt, chunk, nchunks,
                                         (uint32_t*)c->match_part.p, c->p.ratio,
-                                        (slamfe_match2*)c->match_o.p, nullptr, 0,
-                                        nframes > 1 ? nframes - 1 : 1, slot_base,
+                                        (slamfe_match2*)c->match_o.p, nullptr, 0, np, slot_base,
                                         nframes > 1 ? slot_base + 1 : slot_base, c->nslots));
             break;
         }

@@ -545,107 +545,149 @@ struct slamfe_pair_slots {
     int q_base, t_base, nslots;
 };
 
+// One 256-bit comparison and top-2 update: 8 v_xor + 8 chained accumulating
+// v_bcnt + key pack + v_min + v_med3 = 19 VALU operations.
+__device__ __forceinline__ void match_row(const uint32_t (&q)[8], const uint32_t (&t)[8], uint32_t j,
+                                          uint32_t& b1, uint32_t& b2)
+{
+    uint32_t d, x0 = q[0] ^ t[0];
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x0));
+#pragma unroll
+    for (int e = 1; e < 8; ++e) {
+        uint32_t x = q[e] ^ t[e];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+    }
+    uint32_t key = (d << SLAMFE_MKEY_SHIFT) | j;
+    // b1 <= b2 always, so the new second best is the median of (key, b1, b2)
+    uint32_t nb2;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(nb2) : "v"(key), "v"(b1), "v"(b2));
+    b1 = min(key, b1);
+    b2 = nb2;
+}
+
+// Train rows are staged through LDS in blocks of 128 rows (4 KiB, one 16-byte
+// piece per thread, coalesced); every lane then reads the same row address
+// (an LDS broadcast: no bank conflicts), two ds_read_b128 per row, so the row
+// sits in 8 VGPRs while QPT comparisons use it.  The next block's global load
+// is issued before the current block is consumed and written to the other LDS
+// buffer afterwards.
+#define MATCH_STAGE_ROWS 128
+
+// Work decomposition: one workgroup = (pair, block of 256*QPT queries, chunk of
+// chunk_rows train rows).  The grid is one-dimensional and sized for the
+// capacity; a workgroup derives its work item from the *actual* row counts so
+// that the busy workgroups are the first ones of the grid: workgroups are dealt
+// round-robin to the 8 XCDs, and a grid whose idle workgroups recur with a
+// period of 8 would leave whole XCDs empty.
+struct slamfe_match_geo {
+    int cap;        // row capacity of a frame slot / of the query array
+    int chunk_rows; // train rows per workgroup
+    int nchunks;    // chunks the partial buffer is laid out for
+    int npairs;
+    int part_sq, part_sc; // partial index = chunk * part_sc + query * part_sq (uint2 units)
+};
+
 template <int QPT>
 __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ query, int nq_imm,
                                                const int32_t* __restrict__ nq_dev,
                                                const uint32_t* __restrict__ train, int nt_imm,
-                                               const int32_t* __restrict__ nt_dev, int cap,
-                                               int chunk_rows, uint32_t* __restrict__ part,
-                                               slamfe_pair_slots ps, int nchunks)
+                                               const int32_t* __restrict__ nt_dev,
+                                               uint32_t* __restrict__ part, slamfe_pair_slots ps,
+                                               slamfe_match_geo mg)
 {
+    __shared__ uint4 stage[2][MATCH_STAGE_ROWS * 2];
+    const int pair = (int)(blockIdx.x % (unsigned)mg.npairs);
+    const int local = (int)(blockIdx.x / (unsigned)mg.npairs);
     if (ps.nslots) {
-        int sq = (ps.q_base + (int)blockIdx.z) % ps.nslots, st = (ps.t_base + (int)blockIdx.z) % ps.nslots;
-        query += (size_t)sq * cap * 8;
-        train += (size_t)st * cap * 8;
+        int sq = (ps.q_base + pair) % ps.nslots, st = (ps.t_base + pair) % ps.nslots;
+        query += (size_t)sq * mg.cap * 8;
+        train += (size_t)st * mg.cap * 8;
         nq_dev += sq;
         nt_dev += st;
-        part += (size_t)blockIdx.z * nchunks * cap * 2;
+        part += (size_t)pair * mg.nchunks * mg.cap * 2;
     }
-    int nq = nq_dev ? min(*nq_dev, cap) : nq_imm;
-    int nt = nt_dev ? min(*nt_dev, cap) : nt_imm;
-    const int qbase = (blockIdx.x * 256 + threadIdx.x) * QPT;
-    if (blockIdx.x * 256 * QPT >= nq) return;
-    const int j0 = blockIdx.y * chunk_rows;
-    const int j1 = min(nt, j0 + chunk_rows);
+    const int nq = nq_dev ? min(*nq_dev, mg.cap) : nq_imm;
+    const int nt = nt_dev ? min(*nt_dev, mg.cap) : nt_imm;
+    const int real_q = (nq + 256 * QPT - 1) / (256 * QPT);
+    const int real_c = max(1, (nt + mg.chunk_rows - 1) / mg.chunk_rows);
+    if (local >= real_q * real_c) return;
+    const int qb = local / real_c, chunk = local - qb * real_c;
+    const int tid = threadIdx.x;
+    const int qbase = qb * 256 * QPT + tid; // lane owns queries qbase, qbase + 256, ...
+    const int j0 = chunk * mg.chunk_rows;
+    const int j1 = min(nt, j0 + mg.chunk_rows);
     uint32_t q[QPT][8];
     uint32_t b1[QPT], b2[QPT];
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
-        int qi = min(qbase + i, nq - 1);
+        int qi = min(qbase + i * 256, nq - 1);
         const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 8);
         uint4 lo = p[0], hi = p[1];
         q[i][0] = lo.x; q[i][1] = lo.y; q[i][2] = lo.z; q[i][3] = lo.w;
         q[i][4] = hi.x; q[i][5] = hi.y; q[i][6] = hi.z; q[i][7] = hi.w;
         b1[i] = b2[i] = SLAMFE_MKEY_NONE;
     }
-    for (int j = j0; j < j1; ++j) {
-        const uint32_t* t = train + (size_t)j * 8; // wave-uniform
-        uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6],
-                 t7 = t[7];
+    if (j0 < j1) { // uniform per workgroup
+        const uint4* t4 = reinterpret_cast<const uint4*>(train);
+        const int nstages = (j1 - j0 + MATCH_STAGE_ROWS - 1) / MATCH_STAGE_ROWS;
+        // piece `tid` of a stage = 16 bytes at row (tid >> 1), half (tid & 1)
+        auto load_piece = [&](int st) -> uint4 {
+            int row = j0 + st * MATCH_STAGE_ROWS + (tid >> 1);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < j1) v = t4[(size_t)row * 2 + (tid & 1)];
+            return v;
+        };
+        stage[0][tid] = load_piece(0);
+        __syncthreads();
+        for (int st = 0; st < nstages; ++st) {
+            const int cur = st & 1;
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            if (st + 1 < nstages) nxt = load_piece(st + 1);
+            const int jb = j0 + st * MATCH_STAGE_ROWS;
+            const int rows = min(MATCH_STAGE_ROWS, j1 - jb);
+            const uint4* sp = stage[cur];
+            int r = 0;
+            for (; r + 4 <= rows; r += 4) {
 #pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            uint32_t d = __popc(q[i][0] ^ t0);
-            d += __popc(q[i][1] ^ t1);
-            d += __popc(q[i][2] ^ t2);
-            d += __popc(q[i][3] ^ t3);
-            d += __popc(q[i][4] ^ t4);
-            d += __popc(q[i][5] ^ t5);
-            d += __popc(q[i][6] ^ t6);
-            d += __popc(q[i][7] ^ t7);
-            uint32_t key = (d << SLAMFE_MKEY_SHIFT) | (uint32_t)j;
-            uint32_t nb1 = min(key, b1[i]);
-            // new second best = median of (key, b1, b2) because b1 <= b2
-            uint32_t mx = max(key, b1[i]);
-            b2[i] = min(mx, b2[i]);
-            b1[i] = nb1;
+                for (int u = 0; u < 4; ++u) {
+                    uint4 lo = sp[(r + u) * 2], hi = sp[(r + u) * 2 + 1];
+                    const uint32_t tr[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int i = 0; i < QPT; ++i)
+                        match_row(q[i], tr, (uint32_t)(jb + r + u), b1[i], b2[i]);
+                }
+            }
+            for (; r < rows; ++r) {
+                uint4 lo = sp[r * 2], hi = sp[r * 2 + 1];
+                const uint32_t tr[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int i = 0; i < QPT; ++i) match_row(q[i], tr, (uint32_t)(jb + r), b1[i], b2[i]);
+            }
+            if (st + 1 < nstages) stage[cur ^ 1][tid] = nxt;
+            __syncthreads();
         }
     }
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
-        int qi = qbase + i;
+        int qi = qbase + i * 256;
         if (qi < nq) {
             uint2 o = make_uint2(b1[i], b2[i]);
-            reinterpret_cast<uint2*>(part)[(size_t)blockIdx.y * cap + qi] = o;
+            reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] = o;
         }
     }
 }
 
-// Fold per-chunk top-2 keys.  Output either match rows (ratio test applied) or
-// 64-bit shard keys (distance << 32 | global train index).
-__global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict__ part, int nchunks,
-                                                     int cap, int nq_imm,
-                                                     const int32_t* __restrict__ nq_dev,
-                                                     const int32_t* __restrict__ nt_dev, int nt_imm,
-                                                     int chunk_rows, float ratio,
-                                                     slamfe_match2* __restrict__ out,
-                                                     uint64_t* __restrict__ out_keys,
-                                                     int64_t train_base, slamfe_pair_slots ps)
+__device__ __forceinline__ void top2_push(uint32_t k, uint32_t& b1, uint32_t& b2)
 {
-    if (ps.nslots) {
-        int sq = (ps.q_base + (int)blockIdx.z) % ps.nslots, st = (ps.t_base + (int)blockIdx.z) % ps.nslots;
-        nq_dev += sq;
-        nt_dev += st;
-        part += (size_t)blockIdx.z * nchunks * cap * 2;
-        out += (size_t)blockIdx.z * cap;
-    }
-    int nq = nq_dev ? min(*nq_dev, cap) : nq_imm;
-    int nt = nt_dev ? min(*nt_dev, cap) : nt_imm;
-    int qi = blockIdx.x * 256 + threadIdx.x;
-    if (qi >= nq) return;
-    int used = (nt + chunk_rows - 1) / chunk_rows;
-    if (used > nchunks) used = nchunks;
-    uint32_t b1 = SLAMFE_MKEY_NONE, b2 = SLAMFE_MKEY_NONE;
-    for (int c = 0; c < used; ++c) {
-        uint2 p = reinterpret_cast<const uint2*>(part)[(size_t)c * cap + qi];
-        uint32_t k = p.x;
-        uint32_t mx = max(k, b1);
-        b1 = min(k, b1);
-        b2 = min(mx, b2);
-        k = p.y;
-        mx = max(k, b1);
-        b1 = min(k, b1);
-        b2 = min(mx, b2);
-    }
+    uint32_t mx = max(k, b1);
+    b1 = min(k, b1);
+    b2 = min(mx, b2);
+}
+
+__device__ __forceinline__ void match_emit(uint32_t b1, uint32_t b2, int qi, float ratio,
+                                           slamfe_match2* __restrict__ out,
+                                           uint64_t* __restrict__ out_keys, int64_t train_base)
+{
     const uint32_t mask = (1u << SLAMFE_MKEY_SHIFT) - 1u;
     if (out_keys) {
         uint64_t k0 = ~0ULL, k1 = ~0ULL;
@@ -666,6 +708,63 @@ __global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict_
         m.ratio_pass = (uint8_t)(m.nfound == 2 && (float)m.d0 < ratio * (float)m.d1);
         m.reserved[0] = m.reserved[1] = 0;
         out[qi] = m;
+    }
+}
+
+// Fold per-chunk top-2 keys.  Output either match rows (ratio test applied) or
+// 64-bit shard keys (distance << 32 | global train index).
+// LPQ = lanes per query: 1 (a thread walks the few chunks of a frame pair) or
+// 64 (a wavefront strides over the hundreds of chunks of a large train set and
+// folds with a shuffle butterfly; partials are then laid out query-major so the
+// wave reads contiguous keys).
+template <int LPQ>
+__global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict__ part, int nq_imm,
+                                                     const int32_t* __restrict__ nq_dev,
+                                                     const int32_t* __restrict__ nt_dev, int nt_imm,
+                                                     float ratio, slamfe_match2* __restrict__ out,
+                                                     uint64_t* __restrict__ out_keys,
+                                                     int64_t train_base, slamfe_pair_slots ps,
+                                                     slamfe_match_geo mg)
+{
+    const int pair = blockIdx.y;
+    if (ps.nslots) {
+        int sq = (ps.q_base + pair) % ps.nslots, st = (ps.t_base + pair) % ps.nslots;
+        nq_dev += sq;
+        nt_dev += st;
+        part += (size_t)pair * mg.nchunks * mg.cap * 2;
+        out += (size_t)pair * mg.cap;
+    }
+    const int nq = nq_dev ? min(*nq_dev, mg.cap) : nq_imm;
+    const int nt = nt_dev ? min(*nt_dev, mg.cap) : nt_imm;
+    const int used = max(1, (nt + mg.chunk_rows - 1) / mg.chunk_rows);
+    const uint2* p2 = reinterpret_cast<const uint2*>(part);
+    uint32_t b1 = SLAMFE_MKEY_NONE, b2 = SLAMFE_MKEY_NONE;
+    if (LPQ == 1) {
+        int qi = blockIdx.x * 256 + threadIdx.x;
+        if (qi >= nq) return;
+        for (int c = 0; c < used; ++c) {
+            uint2 p = p2[(size_t)c * mg.part_sc + (size_t)qi * mg.part_sq];
+            top2_push(p.x, b1, b2);
+            top2_push(p.y, b1, b2);
+        }
+        match_emit(b1, b2, qi, ratio, out, out_keys, train_base);
+    } else {
+        int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (qi >= nq) return;
+        for (int c = lane; c < used; c += 64) {
+            uint2 p = p2[(size_t)c * mg.part_sc + (size_t)qi * mg.part_sq];
+            top2_push(p.x, b1, b2);
+            top2_push(p.y, b1, b2);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t o1 = (uint32_t)__shfl_xor((int)b1, o), o2 = (uint32_t)__shfl_xor((int)b2, o);
+            uint32_t mx = max(b1, o1);
+            b1 = min(b1, o1);
+            b2 = min(mx, min(b2, o2));
+        }
+        if (lane == 0) match_emit(b1, b2, qi, ratio, out, out_keys, train_base);
     }
 }
 
@@ -930,17 +1029,22 @@ int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes,
     return 0;
 }
 
-int slamfe_match_plan(int nq_max, int nt_max, int* qpt, int* chunk_rows, int* nchunks)
+int slamfe_match_plan(int nq_max, int nt_max, int npairs, int* qpt, int* chunk_rows, int* nchunks)
 {
-    // enough workgroups to fill 256 CUs several times over, chunks >= 64 rows
-    int q = nq_max >= 16384 ? 2 : 1;
+    // Aim for ~4096 workgroups (256 CUs x 2 resident x 8 in flight) so every
+    // SIMD holds several waves; never cut the train set below 64 rows a chunk
+    // (each workgroup first loads 256*QPT query rows, which must be amortised).
+    if (npairs < 1) npairs = 1;
+    int q = nq_max >= 8192 ? 4 : (nq_max >= 2048 ? 2 : 1);
+    if ((long long)nq_max * npairs < 64 * 1024) q = nq_max >= 1024 ? 2 : 1;
     int qblocks = (nq_max + 256 * q - 1) / (256 * q);
     if (qblocks < 1) qblocks = 1;
-    int want = 2048 / qblocks;
+    long long have = (long long)qblocks * npairs;
+    int want = (int)((8192 + have - 1) / have);
     if (want < 1) want = 1;
     int rows = (nt_max + want - 1) / want;
-    if (rows < 64) rows = 64;
-    rows = (rows + 63) / 64 * 64;
+    if (rows < 128) rows = 128;
+    rows = (rows + 127) / 128 * 128; // whole LDS stages
     int nc = (nt_max + rows - 1) / rows;
     if (nc < 1) nc = 1;
     *qpt = q;
@@ -958,19 +1062,31 @@ int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int
     int nq_grid = d_nq ? cap : nq;
     if (nq_grid <= 0 || npairs <= 0) return 0;
     slamfe_pair_slots ps = {q_slot_base, t_slot_base, nslots};
-    dim3 grid((nq_grid + 256 * qpt - 1) / (256 * qpt), nchunks, npairs);
+    const bool wide = nchunks > 32; // many chunks: wave-per-query merge, query-major partials
+    slamfe_match_geo mg;
+    mg.cap = cap;
+    mg.chunk_rows = chunk_rows;
+    mg.nchunks = nchunks;
+    mg.npairs = npairs;
+    mg.part_sq = wide ? nchunks : 1;
+    mg.part_sc = wide ? 1 : cap;
+    int qblocks = (nq_grid + 256 * qpt - 1) / (256 * qpt);
+    dim3 grid((unsigned)qblocks * (unsigned)nchunks * (unsigned)npairs);
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(d_query);
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(d_train);
-    if (qpt == 2)
-        hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, cap,
-                           chunk_rows, part, ps, nchunks);
+    if (qpt == 4)
+        hipLaunchKernelGGL(k_match<4>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
+    else if (qpt == 2)
+        hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
     else
-        hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, cap,
-                           chunk_rows, part, ps, nchunks);
+        hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_match_merge, dim3((nq_grid + 255) / 256, 1, npairs), dim3(256), 0, s, part,
-                       nchunks, cap, nq, d_nq, d_nt, nt, chunk_rows, ratio, d_out, d_keys, train_base,
-                       ps);
+    if (wide)
+        hipLaunchKernelGGL(k_match_merge<64>, dim3((nq_grid + 3) / 4, npairs), dim3(256), 0, s, part, nq,
+                           d_nq, d_nt, nt, ratio, d_out, d_keys, train_base, ps, mg);
+    else
+        hipLaunchKernelGGL(k_match_merge<1>, dim3((nq_grid + 255) / 256, npairs), dim3(256), 0, s, part,
+                           nq, d_nq, d_nt, nt, ratio, d_out, d_keys, train_base, ps, mg);
     LAUNCH_CHECK();
     return 0;
 }
