@@ -207,10 +207,9 @@ int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamf
  * milliseconds per repetition.  Every stage is idempotent on the resident
  * data, so the frame results are unchanged afterwards. */
 #define SLAMFE_STAGE_PYRAMID 1
-#define SLAMFE_STAGE_FAST 2
+#define SLAMFE_STAGE_FAST 2 /* fused FAST + NMS + blur kernel */
 #define SLAMFE_STAGE_SELECT 3
 #define SLAMFE_STAGE_ORIENT 4
-#define SLAMFE_STAGE_BLUR 5
 #define SLAMFE_STAGE_DESCRIBE 6
 #define SLAMFE_STAGE_MATCH 7
 int slamfe_debug_time_stage(slamfe_ctx* ctx, int stage, int nframes, int reps, float* avg_ms);

@@ -272,14 +272,13 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
                                  g.frame_bytes, g.lv[0].pitch));
     KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
-    KCHK(c, slamfe_launch_fast(s, g, n, c->pyr, c->p.fast_threshold, c->p.edge_threshold, c->cand,
-                               c->cand_cnt, c->hist));
+    KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
+                                    c->p.edge_threshold, c->cand, c->cand_cnt, c->hist));
     KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->hist, c->band_cnt, c->level_kept,
                                  c->level_cutoff, slot_base, c->nslots, c->kp_key, c->kp_level,
                                  c->kp_count, c->max_kp, c->sort_lds));
     KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
                                  c->kp_count, c->kps, c->max_kp, c->p.mode, c->p.patch_size));
-    KCHK(c, slamfe_launch_blur(s, g, n, c->pyr, c->blur));
     KCHK(c, slamfe_launch_describe(s, g, n, c->blur, slot_base, c->nslots, c->kp_key, c->kp_level,
                                    c->kp_count, c->kps, c->desc, c->max_kp));
     return SLAMFE_OK;
@@ -727,8 +726,8 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
         case SLAMFE_STAGE_FAST:
             // the histograms are zeroed before every FAST pass, as in the real pipeline
             HIPCHK(c, hipMemsetAsync(c->hist, 0, (size_t)nframes * g.nlevels * 256 * sizeof(uint32_t), s));
-            KCHK(c, slamfe_launch_fast(s, g, nframes, c->pyr, c->p.fast_threshold,
-                                       c->p.edge_threshold, c->cand, c->cand_cnt, c->hist));
+            KCHK(c, slamfe_launch_fast_blur(s, g, nframes, c->pyr, c->blur, c->p.fast_threshold,
+                                            c->p.edge_threshold, c->cand, c->cand_cnt, c->hist));
             break;
         case SLAMFE_STAGE_SELECT:
             KCHK(c, slamfe_launch_select(s, g, nframes, c->cand, c->cand_cnt, c->hist, c->band_cnt,
@@ -739,9 +738,6 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
             KCHK(c, slamfe_launch_orient(s, g, nframes, c->pyr, slot_base, c->nslots, c->kp_key,
                                          c->kp_level, c->kp_count, c->kps, c->max_kp, c->p.mode,
                                          c->p.patch_size));
-            break;
-        case SLAMFE_STAGE_BLUR:
-            KCHK(c, slamfe_launch_blur(s, g, nframes, c->pyr, c->blur));
             break;
         case SLAMFE_STAGE_DESCRIBE:
             KCHK(c, slamfe_launch_describe(s, g, nframes, c->blur, slot_base, c->nslots, c->kp_key,

@@ -14,8 +14,9 @@ int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int s
                          uint32_t frame_bytes, int pitch);
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
                           const uint32_t* taps);
-int slamfe_launch_fast(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                       int thr, int edge, uint32_t* cand, uint32_t* cand_cnt, uint32_t* hist);
+int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
+                            uint32_t* hist);
 int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,
                          const uint32_t* cand_cnt, const uint32_t* hist, uint32_t* band_cnt,
                          uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
@@ -25,8 +26,6 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          int slot_base, int nslots, const uint32_t* kp_key,
                          const uint32_t* kp_level, const int32_t* kp_count, slamfe_keypoint* kps,
                          int max_kp, int mode, int patch_size);
-int slamfe_launch_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                       uint8_t* blur);
 int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* blur,
                            int slot_base, int nslots, const uint32_t* kp_key,
                            const uint32_t* kp_level, const int32_t* kp_count,

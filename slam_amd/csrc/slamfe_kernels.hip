@@ -102,19 +102,35 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, uint8_
 }
 
 // ---------------------------------------------------------------------------
-// K3  FAST-9/16 segment test + score + strict 3x3 NMS + border filter
-//     (detector->detect, Init.cc:76; per level inside cv::ORB)
+// K3+K6  FAST-9/16 (segment test, score, strict 3x3 NMS, border filter) fused
+//        with the 7x7 sigma=2 blur of the same level.
+//        (detector->detect, Init.cc:76, per level inside cv::ORB; and the
+//        GaussianBlur(7x7, 2) cv::ORB applies before describing, Init.cc:78.)
 //
-// One workgroup = one 64x16 tile.  The tile plus a 4-px halo is staged in
-// LDS, scores are computed for the tile plus a 1-px halo, NMS runs on the LDS
-// score tile.  Survivors inside the ORB border go to the tile's own candidate
-// list (no global atomics on lists; order inside a list is arbitrary and fixed
-// by the sort in k_select_write) and into the level's 256-bin score histogram.
+// One workgroup = one 64x16 tile of one level of one frame.  The tile plus a
+// 4-px halo is read from HBM once (aligned dwords, REFLECT_101 at the image
+// border) into LDS and feeds both computations:
+//
+//  FAST   pass B: every pixel of the tile + 1-px ring gets the 4-point
+//                 pretest (any arc of 9 holds one pixel of each opposite pair,
+//                 so both max(p0,p8) and max(p4,p12) must exceed v+t, or both
+//                 mins lie below v-t); survivors are compacted into an LDS list
+//         pass C: full score for list entries only (dense lanes): max over the
+//                 16 arcs of min(d) and of min(-d), minus 1
+//         pass D: NMS of list entries against the LDS score tile; keypoints
+//                 inside the ORB border go to the tile's candidate list and to
+//                 the level's score histogram
+//  blur   rows:   v_dot4_u32_u8 of byte windows cut out with v_alignbyte
+//                 (3.5 VALU ops per output), 16-bit sums to LDS
+//         cols:   v_dot2_u32_u16 per tap, round, saturate, 4 pixels per store
 // ---------------------------------------------------------------------------
-#define FL_W (TW + 8)
-#define FL_H (TH + 8)
-#define FS_W (TW + 2)
+#define FL_W (TW + 8)          /* 72 bytes = 18 dwords per LDS tile row */
+#define FL_WD (FL_W / 4)
+#define FL_H (TH + 8)          /* 24 rows */
+#define FS_W (TW + 2)          /* score tile: 66 x 18 */
 #define FS_H (TH + 2)
+#define FS_N (FS_W * FS_H)     /* 1188 */
+#define BR_H (TH + 6)          /* rows of blur row sums: 22 */
 
 __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
 {
@@ -146,15 +162,20 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
     return m > thr ? m - 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
-                                              int thr, int edge, uint32_t* __restrict__ cand,
-                                              uint32_t* __restrict__ cand_cnt,
-                                              uint32_t* __restrict__ hist)
+__global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
+                                                   uint8_t* __restrict__ blur, int thr, int edge,
+                                                   uint32_t* __restrict__ cand,
+                                                   uint32_t* __restrict__ cand_cnt,
+                                                   uint32_t* __restrict__ hist)
 {
-    __shared__ uint8_t tile[FL_H * FL_W];
-    __shared__ uint8_t sc[FS_H * FS_W];
+    __shared__ uint32_t tile32[FL_H * FL_WD];
+    __shared__ uint32_t sc32[(FS_N + 3) / 4];
+    __shared__ uint32_t rows32[BR_H * TW / 2];
+    __shared__ uint16_t pos[FS_N];
     __shared__ uint32_t list[SLAMFE_TILE_CAND];
-    __shared__ uint32_t nlist;
+    __shared__ uint32_t nlist, npos;
+    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
 
     const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const int l = find_level_by_tile(g, t);
@@ -163,38 +184,124 @@ __global__ __launch_bounds__(256) void k_fast(slamfe_dev_geom g, const uint8_t* 
     const int x0 = (tl % L.tiles_x) * TW, y0 = (tl / L.tiles_x) * TH;
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
 
-    if (tid == 0) nlist = 0;
-    for (int i = tid; i < FL_H * FL_W; i += 256) {
-        int ly = i / FL_W, lx = i - ly * FL_W;
-        int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
-        uint8_t v = 0;
-        if (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) v = img[(size_t)gy * L.pitch + gx];
-        tile[i] = v;
+    if (tid == 0) {
+        nlist = 0;
+        npos = 0;
     }
+    // ---- tile load: 24 rows x 18 dwords, image (y0-4.., x0-4..)
+    for (int i = tid; i < FL_H * FL_WD; i += 256) {
+        int ly = i / FL_WD, dx = i - ly * FL_WD;
+        int gy = reflect101(y0 - 4 + ly, L.h);
+        int gx = x0 - 4 + 4 * dx;
+        const uint8_t* row = img + (size_t)gy * L.pitch;
+        uint32_t v;
+        if (gx >= 0 && gx + 3 < L.w) {
+            v = *reinterpret_cast<const uint32_t*>(row + gx);
+        } else {
+            v = (uint32_t)row[reflect101(gx, L.w)] | ((uint32_t)row[reflect101(gx + 1, L.w)] << 8) |
+                ((uint32_t)row[reflect101(gx + 2, L.w)] << 16) |
+                ((uint32_t)row[reflect101(gx + 3, L.w)] << 24);
+        }
+        tile32[i] = v;
+    }
+    for (int i = tid; i < (FS_N + 3) / 4; i += 256) sc32[i] = 0;
     __syncthreads();
-    for (int i = tid; i < FS_H * FS_W; i += 256) {
+
+    // ---- FAST pass B: pretest on the tile + 1-px ring
+    for (int i = tid; i < FS_N; i += 256) {
         int sy = i / FS_W, sx = i - sy * FS_W;
         int gy = y0 - 1 + sy, gx = x0 - 1 + sx;
-        int s = 0;
-        if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3)
-            s = fast_score_lds(&tile[(sy + 3) * FL_W + sx + 3], thr);
-        sc[i] = (uint8_t)s;
+        if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) {
+            const uint8_t* c = &tile[(sy + 3) * FL_W + sx + 3];
+            int v = c[0];
+            int p0 = c[3 * FL_W], p8 = c[-3 * FL_W], p4 = c[3], p12 = c[-3];
+            int hi = min(max(p0, p8), max(p4, p12));
+            int lo = max(min(p0, p8), min(p4, p12));
+            if (hi > v + thr || lo < v - thr) pos[atomicAdd(&npos, 1u)] = (uint16_t)i;
+        }
+    }
+
+    // ---- blur row pass: task = (row r of 22, group k of 16) -> 4 sums
+    {
+        const uint32_t KA = 18u | (34u << 8) | (49u << 16) | (55u << 24); // taps 0..3
+        const uint32_t KB = 49u | (34u << 8) | (18u << 16);               // taps 4..6, 0
+        for (int i = tid; i < BR_H * 16; i += 256) {
+            int r = i >> 4, k = i & 15;
+            const uint32_t* p = &tile32[(r + 1) * FL_WD + k]; // bytes lx = 4k .. 4k+11
+            uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            // output c = 4k+j reads bytes (j+1 .. j+7) of the 12-byte window
+            uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0, false);
+            s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, s0, false);
+            uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0, false);
+            s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, s1, false);
+            uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0, false);
+            s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, s2, false);
+            uint32_t s3 = __builtin_amdgcn_udot4(d1, KA, 0, false);
+            s3 = __builtin_amdgcn_udot4(d2, KB, s3, false);
+            // sums are <= 257 * 255 = 65535: two per dword
+            uint2 o = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+            *reinterpret_cast<uint2*>(&rows32[r * (TW / 2) + 2 * k]) = o;
+        }
     }
     __syncthreads();
-    uint32_t* hl = hist + ((size_t)f * g.nlevels + l) * 256;
+
+    // ---- FAST pass C: full score of the pretest survivors
+    const uint32_t np = npos;
+    for (uint32_t k = tid; k < np; k += 256) {
+        int i = pos[k];
+        int sy = i / FS_W, sx = i - sy * FS_W;
+        sc[i] = (uint8_t)fast_score_lds(&tile[(sy + 3) * FL_W + sx + 3], thr);
+    }
+
+    // ---- blur column pass: task = (row r of 16, group k of 16) -> 4 pixels
+    {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        constexpr int K[7] = SLAMFE_GAUSS7_INIT;
+        int r = tid >> 4, k = tid & 15;
+        int gy = y0 + r, gx = x0 + 4 * k;
+        if (gy < L.h && gx < L.w) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int py = (tid >> 6) + 4 * k, px = tid & 63;
-        const uint8_t* p = &sc[(py + 1) * FS_W + px + 1];
-        int s = p[0];
-        int m = max(max(max(p[-1], p[1]), max(p[-FS_W - 1], p[-FS_W])),
-                    max(max(p[-FS_W + 1], p[FS_W - 1]), max(p[FS_W], p[FS_W + 1])));
-        int gx = x0 + px, gy = y0 + py;
-        bool keep = s > m && gx >= edge && gx < L.w - edge && gy >= edge && gy < L.h - edge;
-        if (keep) {
-            uint32_t pos = atomicAdd(&nlist, 1u);
-            list[pos] = SLAMFE_KEY(gx, gy, s);
-            atomicAdd(&hl[s], 1u);
+            for (int i = 0; i < 7; ++i) {
+                uint2 v = *reinterpret_cast<const uint2*>(&rows32[(r + i) * (TW / 2) + 2 * k]);
+                us2 lo, hi, klo, khi;
+                lo.x = (unsigned short)v.x; lo.y = (unsigned short)(v.x >> 16);
+                hi.x = (unsigned short)v.y; hi.y = (unsigned short)(v.y >> 16);
+                klo.x = (unsigned short)K[i]; klo.y = 0;
+                khi.x = 0; khi.y = (unsigned short)K[i];
+                a0 = __builtin_amdgcn_udot2(lo, klo, a0, false);
+                a1 = __builtin_amdgcn_udot2(lo, khi, a1, false);
+                a2 = __builtin_amdgcn_udot2(hi, klo, a2, false);
+                a3 = __builtin_amdgcn_udot2(hi, khi, a3, false);
+            }
+            a0 = min((a0 + 32768u) >> 16, 255u);
+            a1 = min((a1 + 32768u) >> 16, 255u);
+            a2 = min((a2 + 32768u) >> 16, 255u);
+            a3 = min((a3 + 32768u) >> 16, 255u);
+            uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off + (size_t)gy * L.pitch + gx;
+            // rows are padded to a multiple of 64 bytes, so the dword store stays
+            // inside the row even when it covers pixels beyond w
+            *reinterpret_cast<uint32_t*>(out) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+        }
+    }
+    __syncthreads();
+
+    // ---- FAST pass D: NMS of the survivors, border filter, emission
+    uint32_t* hl = hist + ((size_t)f * g.nlevels + l) * 256;
+    for (uint32_t k = tid; k < np; k += 256) {
+        int i = pos[k];
+        int s = sc[i];
+        int sy = i / FS_W, sx = i - sy * FS_W;
+        if (s > 0 && sy >= 1 && sy <= TH && sx >= 1 && sx <= TW) {
+            const uint8_t* p = &sc[i];
+            int m = max(max(max(p[-1], p[1]), max(p[-FS_W - 1], p[-FS_W])),
+                        max(max(p[-FS_W + 1], p[FS_W - 1]), max(p[FS_W], p[FS_W + 1])));
+            int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+            if (s > m && gx >= edge && gx < L.w - edge && gy >= edge && gy < L.h - edge) {
+                uint32_t q = atomicAdd(&nlist, 1u);
+                list[q] = SLAMFE_KEY(gx, gy, s);
+                atomicAdd(&hl[s], 1u);
+            }
         }
     }
     __syncthreads();
@@ -426,56 +533,6 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
         k.response = (float)SLAMFE_KEY_S(key);
         k.class_id = -1;
         kps[(size_t)slot * max_kp + idx] = k;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K6  7x7 sigma=2 Gaussian, 8-bit fixed point, BORDER_REFLECT_101
-//     (GaussianBlur(workingMat, ..., Size(7,7), 2, 2) inside cv::ORB)
-// ---------------------------------------------------------------------------
-#define BL_W (TW + 6)
-#define BL_H (TH + 6)
-
-__global__ __launch_bounds__(256) void k_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
-                                              uint8_t* __restrict__ blur)
-{
-    __shared__ uint8_t tile[BL_H * BL_W];
-    __shared__ uint16_t rows[BL_H * TW];
-    constexpr int K[7] = SLAMFE_GAUSS7_INIT;
-    const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-    const int l = find_level_by_tile(g, t);
-    const slamfe_dev_level L = g.lv[l];
-    const int tl = t - L.tile_base;
-    const int x0 = (tl % L.tiles_x) * TW, y0 = (tl / L.tiles_x) * TH;
-    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
-    uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off;
-
-    for (int i = tid; i < BL_H * BL_W; i += 256) {
-        int ly = i / BL_W, lx = i - ly * BL_W;
-        int gy = reflect101(y0 - 3 + ly, L.h), gx = reflect101(x0 - 3 + lx, L.w);
-        tile[i] = img[(size_t)gy * L.pitch + gx];
-    }
-    __syncthreads();
-    for (int i = tid; i < BL_H * TW; i += 256) {
-        int ly = i / TW, lx = i - ly * TW;
-        const uint8_t* p = &tile[ly * BL_W + lx];
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) acc += K[k] * p[k];
-        rows[i] = (uint16_t)acc; // <= 257 * 255 = 65535
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int py = (tid >> 6) + 4 * r, px = tid & 63;
-        int gx = x0 + px, gy = y0 + py;
-        if (gx < L.w && gy < L.h) {
-            int acc = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) acc += K[k] * (int)rows[(py + k) * TW + px];
-            int v = (acc + (1 << 15)) >> 16;
-            out[(size_t)gy * L.pitch + gx] = (uint8_t)(v > 255 ? 255 : v);
-        }
     }
 }
 
@@ -974,11 +1031,12 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
     return 0;
 }
 
-int slamfe_launch_fast(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                       int thr, int edge, uint32_t* cand, uint32_t* cand_cnt, uint32_t* hist)
+int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
+                            uint32_t* hist)
 {
-    hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, thr, edge, cand,
-                       cand_cnt, hist);
+    hipLaunchKernelGGL(k_fast_blur, dim3(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur, thr,
+                       edge, cand, cand_cnt, hist);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1006,14 +1064,6 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
 {
     hipLaunchKernelGGL(k_orient, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, pyr,
                        slot_base, nslots, kp_key, kp_level, kp_count, kps, max_kp, mode, patch_size);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-int slamfe_launch_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                       uint8_t* blur)
-{
-    hipLaunchKernelGGL(k_blur, dim3(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur);
     LAUNCH_CHECK();
     return 0;
 }
