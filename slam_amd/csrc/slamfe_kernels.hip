@@ -207,17 +207,84 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     for (int i = tid; i < (FS_N + 3) / 4; i += 256) sc32[i] = 0;
     __syncthreads();
 
-    // ---- FAST pass B: pretest on the tile + 1-px ring
-    for (int i = tid; i < FS_N; i += 256) {
-        int sy = i / FS_W, sx = i - sy * FS_W;
-        int gy = y0 - 1 + sy, gx = x0 - 1 + sx;
-        if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) {
-            const uint8_t* c = &tile[(sy + 3) * FL_W + sx + 3];
-            int v = c[0];
-            int p0 = c[3 * FL_W], p8 = c[-3 * FL_W], p4 = c[3], p12 = c[-3];
-            int hi = min(max(p0, p8), max(p4, p12));
-            int lo = max(min(p0, p8), min(p4, p12));
-            if (hi > v + thr || lo < v - thr) pos[atomicAdd(&npos, 1u)] = (uint16_t)i;
+    // ---- FAST pass B: pretest on the tile + 1-px ring, 4 pixels per task.
+    // Task = (score row sy of 18, dword column m of 18); its pixels are LDS
+    // bytes lx = 4m .. 4m+3 of row ly = sy + 3.  Bytes are widened to two
+    // 16-bit pairs (pixels 0,2 and 1,3) so that packed 16-bit min / max / sub
+    // handle two pixels per operation; a negative difference flags a survivor.
+    {
+        typedef short v2s __attribute__((ext_vector_type(2)));
+        union pk { uint32_t u; v2s v; };
+        const int blo = max(3, edge - 1);
+        // tiles that lie entirely in the discarded border band skip FAST
+        const bool any_fast = x0 + TW + 1 > blo && x0 - 1 < L.w - blo && y0 + TH + 1 > blo &&
+                              y0 - 1 < L.h - blo;
+        for (int i = tid; any_fast && i < FS_H * FL_WD; i += 256) {
+            int sy = i / FL_WD, m = i - sy * FL_WD;
+            int ly = sy + 3;
+            const uint32_t* row = &tile32[ly * FL_WD + m];
+            uint32_t C = row[0];
+            uint32_t Cp = m > 0 ? row[-1] : 0u;
+            uint32_t Cn = m < FL_WD - 1 ? row[1] : 0u;
+            uint32_t U = row[-3 * FL_WD], D = row[3 * FL_WD];
+            uint32_t L3 = __builtin_amdgcn_alignbyte(C, Cp, 1); // pixels at x-3
+            uint32_t R3 = __builtin_amdgcn_alignbyte(Cn, C, 3); // pixels at x+3
+            uint32_t flags = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                pk v, p0, p8, p4, p12;
+                if (half == 0) {
+                    v.u = C & 0x00ff00ffu; p0.u = D & 0x00ff00ffu; p8.u = U & 0x00ff00ffu;
+                    p4.u = R3 & 0x00ff00ffu; p12.u = L3 & 0x00ff00ffu;
+                } else {
+                    v.u = (C >> 8) & 0x00ff00ffu; p0.u = (D >> 8) & 0x00ff00ffu;
+                    p8.u = (U >> 8) & 0x00ff00ffu; p4.u = (R3 >> 8) & 0x00ff00ffu;
+                    p12.u = (L3 >> 8) & 0x00ff00ffu;
+                }
+                v2s hi = __builtin_elementwise_min(__builtin_elementwise_max(p0.v, p8.v),
+                                                   __builtin_elementwise_max(p4.v, p12.v));
+                v2s lo = __builtin_elementwise_max(__builtin_elementwise_min(p0.v, p8.v),
+                                                   __builtin_elementwise_min(p4.v, p12.v));
+                v2s t2 = {(short)thr, (short)thr};
+                pk r1, r2;
+                r1.v = (v.v + t2) - hi; // < 0  <=>  hi > v + t
+                r2.v = lo - (v.v - t2); // < 0  <=>  lo < v - t
+                uint32_t neg = (r1.u | r2.u) & 0x80008000u;
+                // pair element 0 -> pixel `half`, element 1 -> pixel 2 + half
+                flags |= ((neg >> 15) & 1u) << half;
+                flags |= (neg >> 31) << (2 + half);
+            }
+            // pixel k is a score position iff lx = 4m+k in [3, 68] and the image
+            // position is inside the band that can still yield a keypoint:
+            // keypoints outside [edge, w-edge) x [edge, h-edge) are discarded by
+            // the ORB border filter, and NMS looks one pixel further, so scores
+            // are needed on [lo, w-lo) x [lo, h-lo) with lo = max(3, edge-1)
+            int gy = y0 - 1 + sy, gxb = x0 - 4 + 4 * m;
+            int kmin = max(3 - 4 * m, blo - gxb), kmax = min(FS_W + 2 - 4 * m, L.w - blo - 1 - gxb);
+            kmin = max(kmin, 0);
+            kmax = min(kmax, 3);
+            uint32_t valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
+                                 ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
+            flags &= valid;
+            // wave-level compaction: exclusive prefix of the per-lane counts
+            // (0..4) from three ballots, one LDS atomic per wave
+            const uint32_t c = (uint32_t)__popc(flags);
+            const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u);
+            const unsigned long long act = __ballot(1);
+            uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
+                           2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)) +
+                           4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+            const uint32_t tot = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) + 4u * (uint32_t)__popcll(m2);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+            uint32_t base = 0;
+            if (tot) { // wave-uniform
+                if (rank == 0) base = atomicAdd(&npos, tot);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + pre;
+                int sbase = sy * FS_W + 4 * m - 3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (flags & (1u << k)) pos[base++] = (uint16_t)(sbase + k);
+            }
         }
     }
 
