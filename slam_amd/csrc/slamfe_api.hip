@@ -59,6 +59,8 @@ struct slamfe_ctx {
 
     int max_kp = 0, nslots = 0;
     uint32_t *kp_key = nullptr, *kp_level = nullptr;
+    int32_t* kp_mom = nullptr; // [slots][max_kp][2] intensity-centroid moments
+    float* kp_rot = nullptr;   // [slots][max_kp][2] cos, sin of the keypoint angle
     int32_t* kp_count = nullptr;
     slamfe_keypoint* kps = nullptr;
     uint8_t* desc = nullptr;
@@ -186,10 +188,11 @@ void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
         L.band_base = bands;
         tiles += L.tiles_x * L.tiles_y;
         bands += L.tiles_y;
+        // column taps are read four at a time: 4-entry alignment, zero padding
         L.tap_x = (uint32_t)ntaps;
-        ntaps += (size_t)L.w;
+        ntaps += ((size_t)L.w + 3) / 4 * 4;
         L.tap_y = (uint32_t)ntaps;
-        ntaps += (size_t)L.h;
+        ntaps += ((size_t)L.h + 3) / 4 * 4;
     }
     g->frame_bytes = off;
     g->total_tiles = tiles;
@@ -278,9 +281,10 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
                                  c->level_cutoff, slot_base, c->nslots, c->kp_key, c->kp_level,
                                  c->kp_count, c->max_kp, c->sort_lds));
     KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
-                                 c->kp_count, c->kps, c->max_kp, c->p.mode, c->p.patch_size));
+                                 c->kp_count, c->kp_mom, c->kps, c->kp_rot, c->max_kp, c->p.mode,
+                                 c->p.patch_size));
     KCHK(c, slamfe_launch_describe(s, g, n, c->blur, slot_base, c->nslots, c->kp_key, c->kp_level,
-                                   c->kp_count, c->kps, c->desc, c->max_kp));
+                                   c->kp_count, c->kp_rot, c->desc, c->max_kp));
     return SLAMFE_OK;
 }
 
@@ -342,7 +346,7 @@ void slamfe_destroy(slamfe_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->pyr, c->blur, c->in_stage, c->taps, c->cand, c->cand_cnt, c->hist,
                     c->band_cnt, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
-                    c->kp_count, c->kps, c->desc, c->match_out, c->map_desc, c->match_part.p,
+                    c->kp_count, c->kps, c->desc, c->kp_mom, c->kp_rot, c->match_out, c->map_desc, c->match_part.p,
                     c->match_q.p, c->match_t.p, c->match_o.p, c->pj_idx.p, c->pj_uv.p,
                     c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p};
     for (void* b : bufs)
@@ -361,7 +365,7 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     slamfe_params p = *pin;
     if (p.mode != SLAMFE_MODE_ORB && p.mode != SLAMFE_MODE_PROVIDED) return SLAMFE_E_INVALID;
     if (p.nlevels < 1 || p.nlevels > SLAMFE_MAX_LEVELS) return SLAMFE_E_INVALID;
-    if (p.patch_size != 31 || p.edge_threshold < 19) return SLAMFE_E_INVALID;
+    if (p.patch_size != 31 || p.edge_threshold < 22) return SLAMFE_E_INVALID;
     if (!(p.scale_factor > 1.0f) || p.scale_factor > 2.0f) return SLAMFE_E_INVALID;
     if (p.max_width < 8 || p.max_height < 8 || p.max_width > SLAMFE_MAX_DIM ||
         p.max_height > SLAMFE_MAX_DIM)
@@ -418,6 +422,8 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     HIPCHK(c, hipMalloc(&c->kp_key, S * K * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->kp_level, S * K * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->kp_count, S * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->kp_mom, S * K * 2 * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->kp_rot, S * K * 2 * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->kps, S * K * sizeof(slamfe_keypoint)));
     HIPCHK(c, hipMalloc(&c->desc, S * K * 32));
     HIPCHK(c, hipMemset(c->kp_count, 0, S * sizeof(int32_t)));
@@ -736,12 +742,12 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
             break;
         case SLAMFE_STAGE_ORIENT:
             KCHK(c, slamfe_launch_orient(s, g, nframes, c->pyr, slot_base, c->nslots, c->kp_key,
-                                         c->kp_level, c->kp_count, c->kps, c->max_kp, c->p.mode,
-                                         c->p.patch_size));
+                                         c->kp_level, c->kp_count, c->kp_mom, c->kps, c->kp_rot,
+                                         c->max_kp, c->p.mode, c->p.patch_size));
             break;
         case SLAMFE_STAGE_DESCRIBE:
             KCHK(c, slamfe_launch_describe(s, g, nframes, c->blur, slot_base, c->nslots, c->kp_key,
-                                           c->kp_level, c->kp_count, c->kps, c->desc, c->max_kp));
+                                           c->kp_level, c->kp_count, c->kp_rot, c->desc, c->max_kp));
             break;
         case SLAMFE_STAGE_MATCH: {
             int np = nframes > 1 ? nframes - 1 : 1, qpt, chunk, nchunks;

@@ -23,13 +23,13 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
                          size_t sort_lds_bytes);
 int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                         int slot_base, int nslots, const uint32_t* kp_key,
-                         const uint32_t* kp_level, const int32_t* kp_count, slamfe_keypoint* kps,
+                         int slot_base, int nslots, const uint32_t* kp_key, const uint32_t* kp_level,
+                         const int32_t* kp_count, int32_t* kp_mom, slamfe_keypoint* kps, float* kp_rot,
                          int max_kp, int mode, int patch_size);
 int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* blur,
                            int slot_base, int nslots, const uint32_t* kp_key,
-                           const uint32_t* kp_level, const int32_t* kp_count,
-                           const slamfe_keypoint* kps, uint8_t* desc, int max_kp);
+                           const uint32_t* kp_level, const int32_t* kp_count, const float* kp_rot,
+                           uint8_t* desc, int max_kp);
 
 /* Choose queries per lane and the train chunking for a match of at most
  * nq_max x nt_max rows (npairs independent pairs in one launch); the partial

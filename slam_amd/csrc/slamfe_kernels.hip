@@ -76,29 +76,72 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ in, 
 
 // ---------------------------------------------------------------------------
 // K2  pyramid: level l from level l-1, INTER_LINEAR_EXACT fixed point
-//     taps: ofs | c1 << 16 per destination column / row (host-computed)
+//     (the cumulative resize chain inside cv::ORB).
+//
+// taps: ofs | c1 << 16 per destination column / row (host-computed in double).
+// A lane produces 4 adjacent pixels and stores them as one dword.  The source
+// bytes of a row come from three aligned dwords starting at (ofs[0] & ~3); the
+// two taps of each pixel are cut out with v_alignbyte, widened to a 16-bit pair
+// and combined with their 8.8 weights by v_dot2_u32_u16; the vertical blend of
+// the two 8.8 row results is one more v_dot2 with the rounding constant as the
+// addend:  out = (h0*w0 + h1*w1 + 2^15) >> 16.
 // ---------------------------------------------------------------------------
+typedef unsigned short slamfe_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
+{
+    union { uint32_t u; slamfe_us2 v; } c;
+    c.u = x;
+    return c.v;
+}
+
 __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, uint8_t* __restrict__ pyr,
                                                 const uint32_t* __restrict__ taps)
 {
     const slamfe_dev_level& S = g.lv[l - 1];
     const slamfe_dev_level& D = g.lv[l];
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    int f = blockIdx.z;
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.z;
     if (x >= D.w || y >= D.h) return;
     const uint8_t* src = pyr + (size_t)f * g.frame_bytes + S.off;
     uint8_t* dst = pyr + (size_t)f * g.frame_bytes + D.off;
-    uint32_t tx = taps[D.tap_x + x], ty = taps[D.tap_y + y];
-    uint32_t xo = tx & 0xffffu, c1 = tx >> 16, c0 = 256u - c1;
-    uint32_t yo = ty & 0xffffu, w1 = ty >> 16, w0 = 256u - w1;
-    uint32_t xo1 = xo + (c1 ? 1u : 0u), yo1 = yo + (w1 ? 1u : 0u);
-    const uint8_t* r0 = src + (size_t)yo * S.pitch;
-    const uint8_t* r1 = src + (size_t)yo1 * S.pitch;
-    uint32_t h0 = r0[xo] * c0 + r0[xo1] * c1;
-    uint32_t h1 = r1[xo] * c0 + r1[xo1] * c1;
-    uint32_t v = (h0 * w0 + h1 * w1 + (1u << 15)) >> 16;
-    dst[(size_t)y * D.pitch + x] = (uint8_t)(v > 255u ? 255u : v);
+    // the tap table is padded with zero entries to a multiple of 4 per level
+    const uint4 tx = *reinterpret_cast<const uint4*>(taps + D.tap_x + x);
+    const uint32_t ty = taps[D.tap_y + y];
+    const uint32_t txs[4] = {tx.x, tx.y, tx.z, tx.w};
+    const uint32_t yo = ty & 0xffffu, w1 = ty >> 16, w0 = 256u - w1;
+    const uint32_t yo1 = yo + (w1 ? 1u : 0u);
+    const uint32_t a = (txs[0] & 0xffffu) & ~3u;
+    const uint32_t* r0 = reinterpret_cast<const uint32_t*>(src + (size_t)yo * S.pitch + a);
+    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(src + (size_t)yo1 * S.pitch + a);
+    // 12 source bytes per row; bytes past the row end are read but carry weight 0
+    const uint32_t p0[3] = {r0[0], r0[1], r0[2]};
+    const uint32_t p1[3] = {r1[0], r1[1], r1[2]};
+    const slamfe_us2 wv = as_us2(w0 | (w1 << 16));
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t o = (txs[k] & 0xffffu) - a; // 0 .. 10
+        const uint32_t c1 = txs[k] >> 16;
+        const slamfe_us2 cv = as_us2((256u - c1) | (c1 << 16));
+        const uint32_t sel = o >> 2;
+        uint32_t lo0 = sel == 0 ? p0[0] : (sel == 1 ? p0[1] : p0[2]);
+        uint32_t hi0 = sel == 0 ? p0[1] : (sel == 1 ? p0[2] : 0u);
+        uint32_t lo1 = sel == 0 ? p1[0] : (sel == 1 ? p1[1] : p1[2]);
+        uint32_t hi1 = sel == 0 ? p1[1] : (sel == 1 ? p1[2] : 0u);
+        uint32_t q0 = __builtin_amdgcn_alignbyte(hi0, lo0, o); // bytes o, o+1 in bits 0..15
+        uint32_t q1 = __builtin_amdgcn_alignbyte(hi1, lo1, o);
+        // widen the two taps to a 16-bit pair: 0x00 b1 0x00 b0
+        q0 = __builtin_amdgcn_perm(0u, q0, 0x0c010c00u);
+        q1 = __builtin_amdgcn_perm(0u, q1, 0x0c010c00u);
+        uint32_t h0 = __builtin_amdgcn_udot2(as_us2(q0), cv, 0u, false); // 8.8, <= 65280
+        uint32_t h1 = __builtin_amdgcn_udot2(as_us2(q1), cv, 0u, false);
+        uint32_t v = __builtin_amdgcn_udot2(as_us2(h0 | (h1 << 16)), wv, 1u << 15, false) >> 16;
+        out |= min(v, 255u) << (8 * k);
+    }
+    // rows are padded to a multiple of 64 bytes: the dword store stays in the row
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.pitch + x) = out;
 }
 
 // ---------------------------------------------------------------------------
@@ -532,17 +575,22 @@ __global__ __launch_bounds__(256) void k_select_write(
 }
 
 // ---------------------------------------------------------------------------
-// K5  orientation by intensity centroid (ICAngles inside cv::ORB) and the
-//     final cv::KeyPoint record.  One wavefront per keypoint: the 749-pixel
-//     disc is covered two rows at a time by the two 32-lane halves.
+// K5  orientation by intensity centroid (ICAngles inside cv::ORB).
+//
+// k_orient: one wavefront per keypoint sums the moments of the 749-pixel disc.
+// Each row of the disc (31 bytes starting at cx-15) is read as 9 aligned dwords;
+// a lane masks the bytes outside the disc and gets the row-sum S and the
+// position-weighted sum T of its 4 pixels from two v_dot4_u32_u8:
+//   m10 += u0 * S + T,  m01 += v * S      (u0 = x-offset of the dword's byte 0)
+// k_finish: one lane per keypoint turns the moments into the angle
+// (fastAtan2), its cos/sin for the descriptor, and the cv::KeyPoint record.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
                                                 int slot_base, int nslots,
                                                 const uint32_t* __restrict__ kp_key,
                                                 const uint32_t* __restrict__ kp_level,
                                                 const int32_t* __restrict__ kp_count,
-                                                slamfe_keypoint* __restrict__ kps, int max_kp,
-                                                int mode, int patch_size)
+                                                int2* __restrict__ kp_mom, int max_kp)
 {
     const int f = blockIdx.y;
     const int slot = (slot_base + f) % nslots;
@@ -556,51 +604,83 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
     if (l < 0 || l >= g.nlevels) return; // never true for entries written by k_select_write
     const slamfe_dev_level L = g.lv[l];
     const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
-    if (cx < 16 || cy < 16 || cx >= L.w - 16 || cy >= L.h - 16) return; // patch must be inside
-    float angle = -1.f;
-    if (mode == SLAMFE_MODE_ORB) {
-        const uint8_t* c = pyr + (size_t)f * g.frame_bytes + L.off + (size_t)cy * L.pitch + cx;
-        // half-widths of the disc rows |v| = 0..15, one nibble each
-        const unsigned long long umax = 0x3689abcddeeeffffULL;
-        const int half = lane >> 5, ul = lane & 31, u = ul - 15;
-        int m10 = 0, m01 = 0;
+    if (cx < 19 || cy < 16 || cx >= L.w - 21 || cy >= L.h - 16) return; // patch must be inside
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
+    // half-widths of the disc rows |v| = 0..15, one nibble each
+    const unsigned long long umax = 0x3689abcddeeeffffULL;
+    const int a0 = (cx - 15) & ~3; // aligned start of every row's 36-byte span
+    int m10 = 0, m01 = 0;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            int v = -15 + 2 * it + half;
+    for (int it = 0; it < 5; ++it) {
+        int t = it * 64 + lane; // (row, dword) task, 31 x 9 = 279 of them
+        int row = t / 9, dw = t - row * 9;
+        if (row < 31) {
+            int v = row - 15;
             int av = v < 0 ? -v : v;
-            int d = av <= 15 ? (int)((umax >> (4 * av)) & 15ULL) : -1;
-            int au = u < 0 ? -u : u;
-            if (ul < 31 && au <= d) {
-                int val = c[v * L.pitch + u];
-                m10 += u * val;
-                m01 += v * val;
+            int d = (int)((umax >> (4 * av)) & 15ULL);
+            int u0 = a0 + 4 * dw - cx;
+            int klo = max(-d - u0, 0), khi = min(d - u0, 3);
+            if (khi >= klo) {
+                uint32_t x = *reinterpret_cast<const uint32_t*>(img + (size_t)(cy + v) * L.pitch + a0 + 4 * dw);
+                uint32_t mask = (0xffffffffu >> (8 * (3 - khi))) & (0xffffffffu << (8 * klo));
+                x &= mask;
+                int S = (int)__builtin_amdgcn_udot4(x, 0x01010101u, 0u, false);
+                int T = (int)__builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
+                m10 += u0 * S + T;
+                m01 += v * S;
             }
         }
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
-        }
-        angle = slamfe_fast_atan2((float)m01, (float)m10);
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
     }
-    if (lane == 0) {
-        slamfe_keypoint k;
-        if (mode == SLAMFE_MODE_ORB) {
-            k.x = (float)cx * L.scale;
-            k.y = (float)cy * L.scale;
-            k.size = (float)patch_size * L.scale;
-            k.octave = l;
-        } else {
-            k.x = (float)cx;
-            k.y = (float)cy;
-            k.size = 7.f;
-            k.octave = 0;
-        }
-        k.angle = angle;
-        k.response = (float)SLAMFE_KEY_S(key);
-        k.class_id = -1;
-        kps[(size_t)slot * max_kp + idx] = k;
+    if (lane == 0) kp_mom[(size_t)slot * max_kp + idx] = make_int2(m10, m01);
+}
+
+__global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base, int nslots,
+                                                const uint32_t* __restrict__ kp_key,
+                                                const uint32_t* __restrict__ kp_level,
+                                                const int32_t* __restrict__ kp_count,
+                                                const int2* __restrict__ kp_mom,
+                                                slamfe_keypoint* __restrict__ kps,
+                                                float2* __restrict__ kp_rot, int max_kp, int mode,
+                                                int patch_size)
+{
+    const int f = blockIdx.y;
+    const int slot = (slot_base + f) % nslots;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int n = kp_count[slot];
+    if (n > max_kp) n = max_kp;
+    if (idx >= n) return;
+    const size_t e = (size_t)slot * max_kp + idx;
+    const uint32_t key = kp_key[e];
+    int l = (int)kp_level[e];
+    if (l < 0 || l >= g.nlevels) l = 0;
+    const float scale = g.lv[l].scale;
+    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+    slamfe_keypoint k;
+    if (mode == SLAMFE_MODE_ORB) {
+        int2 m = kp_mom[e];
+        k.angle = slamfe_fast_atan2((float)m.y, (float)m.x);
+        k.x = (float)cx * scale;
+        k.y = (float)cy * scale;
+        k.size = (float)patch_size * scale;
+        k.octave = l;
+    } else {
+        k.angle = -1.f;
+        k.x = (float)cx;
+        k.y = (float)cy;
+        k.size = 7.f;
+        k.octave = 0;
     }
+    k.response = (float)SLAMFE_KEY_S(key);
+    k.class_id = -1;
+    kps[e] = k;
+    float sn, cs;
+    slamfe_sincos_deg(k.angle, &sn, &cs);
+    kp_rot[e] = make_float2(cs, sn);
 }
 
 // ---------------------------------------------------------------------------
@@ -613,7 +693,7 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   const uint32_t* __restrict__ kp_key,
                                                   const uint32_t* __restrict__ kp_level,
                                                   const int32_t* __restrict__ kp_count,
-                                                  const slamfe_keypoint* __restrict__ kps,
+                                                  const float2* __restrict__ kp_rot,
                                                   uint8_t* __restrict__ desc, int max_kp)
 {
     const int f = blockIdx.y;
@@ -629,9 +709,8 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
     const slamfe_dev_level L = g.lv[l];
     const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
     if (cx < 19 || cy < 19 || cx >= L.w - 19 || cy >= L.h - 19) return; // samples reach 18.4 px
-    const float angle = kps[(size_t)slot * max_kp + idx].angle;
-    float a, b; // a = cos, b = sin
-    slamfe_sincos_deg(angle, &b, &a);
+    const float2 rot = kp_rot[(size_t)slot * max_kp + idx];
+    const float a = rot.x, b = rot.y; // cos, sin of the keypoint angle
     const uint8_t* c = blur + (size_t)f * g.frame_bytes + L.off + (size_t)cy * L.pitch + cx;
     unsigned long long word[4];
 #pragma unroll
@@ -1091,7 +1170,7 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
                           const uint32_t* taps)
 {
     for (int l = 1; l < g.nlevels; ++l) {
-        dim3 grid((g.lv[l].w + 63) / 64, (g.lv[l].h + 3) / 4, nframes);
+        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nframes);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, g, l, pyr, taps);
         LAUNCH_CHECK();
     }
@@ -1125,12 +1204,18 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
 }
 
 int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                         int slot_base, int nslots, const uint32_t* kp_key,
-                         const uint32_t* kp_level, const int32_t* kp_count, slamfe_keypoint* kps,
+                         int slot_base, int nslots, const uint32_t* kp_key, const uint32_t* kp_level,
+                         const int32_t* kp_count, int32_t* kp_mom, slamfe_keypoint* kps, float* kp_rot,
                          int max_kp, int mode, int patch_size)
 {
-    hipLaunchKernelGGL(k_orient, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, pyr,
-                       slot_base, nslots, kp_key, kp_level, kp_count, kps, max_kp, mode, patch_size);
+    if (mode == SLAMFE_MODE_ORB) {
+        hipLaunchKernelGGL(k_orient, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, pyr, slot_base,
+                           nslots, kp_key, kp_level, kp_count, reinterpret_cast<int2*>(kp_mom), max_kp);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_finish, dim3((max_kp + 255) / 256, nframes), dim3(256), 0, s, g, slot_base,
+                       nslots, kp_key, kp_level, kp_count, reinterpret_cast<const int2*>(kp_mom), kps,
+                       reinterpret_cast<float2*>(kp_rot), max_kp, mode, patch_size);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1138,10 +1223,11 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
 int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* blur,
                            int slot_base, int nslots, const uint32_t* kp_key,
                            const uint32_t* kp_level, const int32_t* kp_count,
-                           const slamfe_keypoint* kps, uint8_t* desc, int max_kp)
+                           const float* kp_rot, uint8_t* desc, int max_kp)
 {
     hipLaunchKernelGGL(k_describe, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, blur,
-                       slot_base, nslots, kp_key, kp_level, kp_count, kps, desc, max_kp);
+                       slot_base, nslots, kp_key, kp_level, kp_count,
+                       reinterpret_cast<const float2*>(kp_rot), desc, max_kp);
     LAUNCH_CHECK();
     return 0;
 }
