@@ -688,6 +688,9 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
 //     desc->compute, Init.cc:78).  One wavefront per keypoint; lane i evaluates
 //     tests i, 64+i, 128+i, 192+i, so each wave ballot is 8 descriptor bytes.
 // ---------------------------------------------------------------------------
+#define DP_ROWS 37 /* samples reach +-18 px (|pattern| <= 13 * sqrt 2 = 18.4) */
+#define DP_DW 10   /* 37 bytes from an aligned start: 40 bytes = 10 dwords */
+
 __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8_t* __restrict__ blur,
                                                   int slot_base, int nslots,
                                                   const uint32_t* __restrict__ kp_key,
@@ -696,9 +699,13 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   const float2* __restrict__ kp_rot,
                                                   uint8_t* __restrict__ desc, int max_kp)
 {
+    // each wavefront stages the 37-row neighbourhood of its keypoint in LDS with
+    // row-contiguous dword loads, then gathers its 512 samples from LDS
+    __shared__ uint32_t patch32[4][DP_ROWS * DP_DW];
     const int f = blockIdx.y;
     const int slot = (slot_base + f) % nslots;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 4 + wv;
     const int lane = threadIdx.x & 63;
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
@@ -708,10 +715,25 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
     if (l < 0 || l >= g.nlevels) return; // never true for entries written by k_select_write
     const slamfe_dev_level L = g.lv[l];
     const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
-    if (cx < 19 || cy < 19 || cx >= L.w - 19 || cy >= L.h - 19) return; // samples reach 18.4 px
+    if (cx < 22 || cy < 19 || cx >= L.w - 22 || cy >= L.h - 19) return; // patch must be inside
     const float2 rot = kp_rot[(size_t)slot * max_kp + idx];
     const float a = rot.x, b = rot.y; // cos, sin of the keypoint angle
-    const uint8_t* c = blur + (size_t)f * g.frame_bytes + L.off + (size_t)cy * L.pitch + cx;
+    const uint8_t* img = blur + (size_t)f * g.frame_bytes + L.off;
+    const int ax = (cx - 18) & ~3; // aligned start column of the staged rows
+    uint32_t* my = patch32[wv];
+#pragma unroll
+    for (int it = 0; it < (DP_ROWS * DP_DW + 63) / 64; ++it) {
+        int t = it * 64 + lane;
+        int row = t / DP_DW, dw = t - row * DP_DW;
+        if (row < DP_ROWS)
+            my[t] = *reinterpret_cast<const uint32_t*>(img + (size_t)(cy - 18 + row) * L.pitch + ax + 4 * dw);
+    }
+    // only this wavefront reads what it wrote: LDS operations of one wave are
+    // ordered, the fence keeps the compiler from moving the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * (DP_DW * 4) + (cx - ax);
     unsigned long long word[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -719,8 +741,8 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
         float px0 = (float)t[0], py0 = (float)t[1], px1 = (float)t[2], py1 = (float)t[3];
         float x0 = px0 * a - py0 * b, y0 = px0 * b + py0 * a;
         float x1 = px1 * a - py1 * b, y1 = px1 * b + py1 * a;
-        int v0 = c[slamfe_round_f(y0) * L.pitch + slamfe_round_f(x0)];
-        int v1 = c[slamfe_round_f(y1) * L.pitch + slamfe_round_f(x1)];
+        int v0 = c[slamfe_round_f(y0) * (DP_DW * 4) + slamfe_round_f(x0)];
+        int v1 = c[slamfe_round_f(y1) * (DP_DW * 4) + slamfe_round_f(x1)];
         word[j] = __ballot(v0 < v1);
     }
     if (lane < 4) {
@@ -1238,8 +1260,7 @@ int slamfe_match_plan(int nq_max, int nt_max, int npairs, int* qpt, int* chunk_r
     // SIMD holds several waves; never cut the train set below 64 rows a chunk
     // (each workgroup first loads 256*QPT query rows, which must be amortised).
     if (npairs < 1) npairs = 1;
-    int q = nq_max >= 8192 ? 4 : (nq_max >= 2048 ? 2 : 1);
-    if ((long long)nq_max * npairs < 64 * 1024) q = nq_max >= 1024 ? 2 : 1;
+    int q = (long long)nq_max * npairs >= 128 * 1024 ? 4 : (nq_max >= 1024 ? 2 : 1);
     int qblocks = (nq_max + 256 * q - 1) / (256 * q);
     if (qblocks < 1) qblocks = 1;
     long long have = (long long)qblocks * npairs;
