@@ -102,7 +102,11 @@ int slamfe_default_params(slamfe_params* p);
 
 /* Replaces the object construction of Init.cc:64-66. */
 int slamfe_create(const slamfe_params* p, slamfe_ctx** out);
+/* Releases what slamfe_create made (the reference never frees the objects of
+ * Init.cc:64-66; its process simply ends). */
 void slamfe_destroy(slamfe_ctx* ctx);
+/* Text of the last failure on this context: what the cv::Exception thrown
+ * from Init.cc:76 / 78 / 131 would have carried. */
 const char* slamfe_last_error(const slamfe_ctx* ctx);
 
 /* Replaces Init::extractKeyPoints (Init.cc:74-79).
@@ -117,20 +121,22 @@ int slamfe_extract(slamfe_ctx* ctx, const uint8_t* img, int w, int h, int stride
                    slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
                    uint64_t* frame_handle);
 
-/* The same for n <= max_batch frames of one size; frame i uses imgs[i],
+/* Init.cc:75-78 for n <= max_batch frames of one size (the reference takes one
+ * frame per loop iteration, Init.cc:124-130; a batch is n iterations); frame i uses imgs[i],
  * kps + i*cap, desc + i*cap*32, n_out[i], frame_handles[i].  kps and desc may
  * be NULL to leave the results on the device only. */
 int slamfe_extract_batch(slamfe_ctx* ctx, const uint8_t* const* imgs, int n, int w, int h,
                          int stride, int channels, slamfe_keypoint* kps, uint8_t* desc, int cap,
                          int* n_out, uint64_t* frame_handles);
 
-/* Extraction from frames that already sit in device memory (frame i at
+/* Init.cc:75-78 for frames that already sit in device memory (frame i at
  * d_imgs + i*frame_stride_bytes).  Asynchronous on the context's stream; no
  * host synchronisation.  Results stay device-resident under the handles. */
 int slamfe_extract_resident(slamfe_ctx* ctx, const void* d_imgs, int n, int w, int h, int stride,
                             size_t frame_stride_bytes, int channels, uint64_t* frame_handles);
 
-/* Copy a device-resident frame result to the host (synchronises). */
+/* Copy a device-resident frame result (the keypoints / descriptors of
+ * Init.cc:76-78) to the host; synchronises. */
 int slamfe_frame_download(slamfe_ctx* ctx, uint64_t frame_handle, slamfe_keypoint* kps,
                           uint8_t* desc, int cap, int* n_out);
 
@@ -140,12 +146,12 @@ int slamfe_frame_download(slamfe_ctx* ctx, uint64_t frame_handle, slamfe_keypoin
 int slamfe_match_knn2(slamfe_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
                       slamfe_match2* out);
 
-/* The same on two device-resident frames; out may be NULL (result stays on the
+/* Init.cc:131-153 on two device-resident frames; out may be NULL (result stays on the
  * device, readable with slamfe_match_download).  *nq_out = rows written. */
 int slamfe_match_frames(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
                         slamfe_match2* out, int cap, int* nq_out);
 
-/* Asynchronous form: both frames device-resident, result written to
+/* Asynchronous form of Init.cc:131-153: both frames device-resident, result written to
  * d_out[0..max_keypoints) (device memory), row counts read on the device. */
 int slamfe_match_resident(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
                           slamfe_match2* d_out);
@@ -167,7 +173,7 @@ int slamfe_match_resident_batch(slamfe_ctx* ctx, uint64_t first_query, uint64_t 
 int slamfe_match_shard_keys(slamfe_ctx* ctx, const void* d_query, int nq, const void* d_train,
                             int nt, int64_t train_base, uint64_t* d_keys);
 
-/* Merge nshards key sets (laid out [shard][nq][2], e.g. the output of an
+/* Second half of the sharded form of Init.cc:131-153: merge nshards key sets (laid out [shard][nq][2], e.g. the output of an
  * all-gather) into match rows + ratio flag.  Asynchronous. */
 int slamfe_merge_shard_keys(slamfe_ctx* ctx, const uint64_t* d_keys_all, int nshards, int nq,
                             slamfe_match2* d_out);
@@ -192,10 +198,11 @@ int slamfe_search_by_projection(slamfe_ctx* ctx, uint64_t frame, const int32_t* 
                                 const float* uv, const int32_t* point_ids, int R, float radius,
                                 int max_hamming, int32_t* matched_point_id);
 
-/* Wait for everything queued on the context's stream. */
+/* Wait for everything queued on the context's stream (no counterpart in the
+ * reference, whose OpenCV calls are synchronous). */
 int slamfe_sync(slamfe_ctx* ctx);
 
-/* Device pointers of a resident frame (valid until the slot is recycled after
+/* No counterpart in the reference: device pointers of a resident frame (valid until the slot is recycled after
  * frame_slots further frames): keypoints, 32-byte descriptor rows, and the
  * device-side count. */
 int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamfe_keypoint** d_kps,
@@ -221,7 +228,8 @@ int slamfe_debug_time_stage(slamfe_ctx* ctx, int stage, int nframes, int reps, f
 int slamfe_debug_read_level(slamfe_ctx* ctx, int frame_in_batch, int level, int blurred,
                             uint8_t* out, int out_capacity, int* w, int* h);
 
-/* Library version, for the loader's sanity check. */
+/* Library version, for the loader's sanity check (no counterpart in the
+ * reference). */
 int slamfe_version(void);
 
 #ifdef __cplusplus

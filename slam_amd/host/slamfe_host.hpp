@@ -1,0 +1,222 @@
+// slamfe_host.hpp -- header-only C++ host layer over the C ABI of slamfe.h.
+//
+// It gives the reference's tracking thread (Init::processFrames, Init.cc:87-328)
+// the calls it makes today, with the same names, argument order and result
+// types, so that the three call sites can be switched with a few lines:
+//
+//   Init.cc:64-66  detector / desc / matcher creation  -> slamfe::FrontEnd ctor
+//   Init.cc:74-79  Init::extractKeyPoints(frame, keypoints, descriptors)
+//                                                       -> FrontEnd::extractKeyPoints
+//   Init.cc:131    matcher->knnMatch(d1, d2, matches, 2) -> FrontEnd::knnMatch
+//   Init.cc:229-259 the search-by-projection double loop -> FrontEnd::searchByProjection
+//   Init.cc:296    new Point(..., descriptors2.row(idx), ...) -> FrontEnd::mapPut
+//
+// With -DSLAMFE_WITH_OPENCV the types are OpenCV's own (cv::KeyPoint, cv::Mat,
+// cv::DMatch); without it, layout-compatible stand-ins are used so that the
+// layer can be compiled and tested on a machine without OpenCV.
+//
+// Error behaviour: OpenCV reports failures by throwing cv::Exception, which the
+// reference never catches.  This layer throws slamfe::Error (a
+// std::runtime_error) for every non-zero status of the C ABI.
+#ifndef SLAMFE_HOST_HPP
+#define SLAMFE_HOST_HPP
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "slamfe.h"
+
+#ifdef SLAMFE_WITH_OPENCV
+#include <opencv2/core.hpp>
+#include <opencv2/features2d.hpp>
+#endif
+
+namespace slamfe {
+
+#ifdef SLAMFE_WITH_OPENCV
+using KeyPoint = cv::KeyPoint;
+using DMatch = cv::DMatch;
+using Point2f = cv::Point2f;
+#else
+struct Point2f {
+    float x = 0, y = 0;
+    Point2f() = default;
+    Point2f(float x_, float y_) : x(x_), y(y_) {}
+};
+// same 28-byte layout as cv::KeyPoint
+struct KeyPoint {
+    Point2f pt;
+    float size = 0, angle = -1, response = 0;
+    int octave = 0, class_id = -1;
+};
+// same 16-byte layout as cv::DMatch
+struct DMatch {
+    int queryIdx = -1, trainIdx = -1, imgIdx = -1;
+    float distance = 0;
+};
+#endif
+static_assert(sizeof(KeyPoint) == sizeof(slamfe_keypoint), "KeyPoint must match cv::KeyPoint's layout");
+static_assert(sizeof(DMatch) == 16, "DMatch must match cv::DMatch's layout");
+
+// A continuous CV_8U matrix (rows x cols), the shape of `descriptors` in the
+// reference; and the view of an 8-bit image (gray or BGR).
+struct Mat8 {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> data;
+    uint8_t* ptr(int r) { return data.data() + (size_t)r * cols; }
+    const uint8_t* ptr(int r) const { return data.data() + (size_t)r * cols; }
+    bool empty() const { return rows == 0; }
+};
+
+struct ImageView {
+    const uint8_t* data;
+    int width, height, stride, channels; // channels: 1 gray, 3 BGR
+};
+
+class Error : public std::runtime_error {
+public:
+    Error(int code_, const std::string& what_) : std::runtime_error(what_), code(code_) {}
+    int code;
+};
+
+class FrontEnd {
+public:
+    // Same argument meaning as the object creation of Init::Init
+    // (Init.cc:64-66): nfeatures, FAST threshold; the remaining ORB arguments
+    // are the reference's constants (1.2f, 8 levels, edge 31, patch 31).
+    // mode SLAMFE_MODE_PROVIDED reproduces the reference's literal
+    // FAST-then-ORB::compute call pair; SLAMFE_MODE_ORB is full ORB.
+    FrontEnd(int nfeatures, int thold, int maxWidth, int maxHeight, int mode = SLAMFE_MODE_PROVIDED,
+             int device = 0, int mapCapacity = 1 << 16)
+    {
+        slamfe_params p;
+        slamfe_default_params(&p);
+        p.mode = mode;
+        p.nfeatures = nfeatures;
+        p.fast_threshold = thold;
+        p.max_width = maxWidth;
+        p.max_height = maxHeight;
+        p.device_id = device;
+        p.map_capacity = mapCapacity;
+        int rc = slamfe_create(&p, &ctx_);
+        if (rc != SLAMFE_OK) {
+            std::string msg = ctx_ ? slamfe_last_error(ctx_) : "slamfe_create failed";
+            if (ctx_) slamfe_destroy(ctx_);
+            ctx_ = nullptr;
+            throw Error(rc, msg);
+        }
+        capacity_ = mode == SLAMFE_MODE_ORB ? (2 * nfeatures > 4096 ? 2 * nfeatures : 4096) : 32768;
+    }
+    ~FrontEnd()
+    {
+        if (ctx_) slamfe_destroy(ctx_);
+    }
+    FrontEnd(const FrontEnd&) = delete;
+    FrontEnd& operator=(const FrontEnd&) = delete;
+
+    // Init::extractKeyPoints(frame, keypoints, descriptors), Init.cc:74-79.
+    // Returns the handle of the device-resident copy of this frame's result.
+    uint64_t extractKeyPoints(const ImageView& frame, std::vector<KeyPoint>& keypoints, Mat8& descriptors)
+    {
+        keypoints.resize((size_t)capacity_);
+        descriptors.data.resize((size_t)capacity_ * 32);
+        int n = 0;
+        uint64_t handle = 0;
+        check(slamfe_extract(ctx_, frame.data, frame.width, frame.height, frame.stride, frame.channels,
+                             reinterpret_cast<slamfe_keypoint*>(keypoints.data()), descriptors.data.data(),
+                             capacity_, &n, &handle));
+        keypoints.resize((size_t)n);
+        descriptors.rows = n;
+        descriptors.cols = 32;
+        descriptors.data.resize((size_t)n * 32);
+        return handle;
+    }
+
+    // matcher->knnMatch(descriptors1, descriptors2, matches, 2), Init.cc:131:
+    // matches[i] holds up to k = 2 DMatch in (distance, trainIdx) order.
+    void knnMatch(const Mat8& query, const Mat8& train, std::vector<std::vector<DMatch>>& matches, int k = 2)
+    {
+        if (k != 2) throw Error(SLAMFE_E_INVALID, "only k = 2 is implemented (the reference's call)");
+        std::vector<slamfe_match2> rows((size_t)query.rows);
+        check(slamfe_match_knn2(ctx_, query.data.data(), query.rows, train.data.data(), train.rows, rows.data()));
+        matches.assign((size_t)query.rows, {});
+        for (int i = 0; i < query.rows; ++i) {
+            const slamfe_match2& m = rows[(size_t)i];
+            if (m.nfound > 0) matches[(size_t)i].push_back(make(i, m.idx0, m.d0));
+            if (m.nfound > 1) matches[(size_t)i].push_back(make(i, m.idx1, m.d1));
+        }
+    }
+
+    // new Point(id, ..., descriptors2.row(idx), ...), Init.cc:296: mirror the
+    // descriptor row of map point `id` on the device.
+    void mapPut(int id, const uint8_t* desc32)
+    {
+        int32_t pid = id;
+        check(slamfe_map_put(ctx_, &pid, desc32, 1));
+    }
+
+    // The inner search of Init.cc:229-259.  inlierTrainIdx[i] is
+    // goodMatches[i].trainIdx of the i-th entry with mask[i] != 0, in loop order;
+    // rPoints / rPointIds are the reprojected visible points of Init.cc:203-218
+    // (ids = points[rPointsIdx[j]]->id).  Result[i] = id of the map point the
+    // reference would attach keypoint i to, or -1 (then it triangulates).
+    std::vector<int> searchByProjection(uint64_t frameHandle, const std::vector<int>& inlierTrainIdx,
+                                        const std::vector<Point2f>& rPoints, const std::vector<int>& rPointIds,
+                                        float radius = 32.f, int maxHamming = 128)
+    {
+        std::vector<int> out(inlierTrainIdx.size(), -1);
+        if (inlierTrainIdx.empty()) return out;
+        static_assert(sizeof(Point2f) == 8, "Point2f is two floats");
+        check(slamfe_search_by_projection(ctx_, frameHandle, inlierTrainIdx.data(), (int)inlierTrainIdx.size(),
+                                          reinterpret_cast<const float*>(rPoints.data()), rPointIds.data(),
+                                          (int)rPoints.size(), radius, maxHamming, out.data()));
+        return out;
+    }
+
+    slamfe_ctx* ctx() { return ctx_; }
+
+#ifdef SLAMFE_WITH_OPENCV
+    // Drop-in signatures for the reference's own types.
+    uint64_t extractKeyPoints(const cv::Mat& frame, std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors)
+    {
+        CV_Assert(frame.depth() == CV_8U && (frame.channels() == 1 || frame.channels() == 3));
+        ImageView v{frame.data, frame.cols, frame.rows, (int)frame.step, frame.channels()};
+        Mat8 d;
+        uint64_t h = extractKeyPoints(v, keypoints, d);
+        descriptors.create(d.rows, 32, CV_8U); // fresh buffer: no aliasing with the previous frame
+        if (d.rows) std::memcpy(descriptors.data, d.data.data(), d.data.size());
+        return h;
+    }
+    void knnMatch(const cv::Mat& query, const cv::Mat& train, std::vector<std::vector<cv::DMatch>>& matches, int k)
+    {
+        CV_Assert(query.isContinuous() && train.isContinuous() && query.cols == 32 && train.cols == 32);
+        Mat8 q, t;
+        q.rows = query.rows; q.cols = 32; q.data.assign(query.data, query.data + (size_t)query.rows * 32);
+        t.rows = train.rows; t.cols = 32; t.data.assign(train.data, train.data + (size_t)train.rows * 32);
+        knnMatch(q, t, matches, k);
+    }
+#endif
+
+private:
+    static DMatch make(int q, int t, int d)
+    {
+        DMatch m;
+        m.queryIdx = q;
+        m.trainIdx = t;
+        m.imgIdx = 0;
+        m.distance = (float)d;
+        return m;
+    }
+    void check(int rc)
+    {
+        if (rc != SLAMFE_OK) throw Error(rc, slamfe_last_error(ctx_));
+    }
+    slamfe_ctx* ctx_ = nullptr;
+    int capacity_ = 0;
+};
+
+} // namespace slamfe
+#endif

@@ -1,0 +1,121 @@
+// Drives the C++ host layer the way Init::processFrames drives OpenCV
+// (Init.cc:113, 130-153, 229-259) on two synthetic frames and checks every
+// result against the CPU checker.  Exit code 0 = identical.
+// usage: test_host_adapter frameA.raw frameB.raw width height
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "slamfe_host.hpp"
+#include "slamfe_oracle.h"
+
+static std::vector<uint8_t> read_file(const char* path, size_t n)
+{
+    std::vector<uint8_t> v(n);
+    FILE* f = std::fopen(path, "rb");
+    if (!f || std::fread(v.data(), 1, n, f) != n) {
+        std::fprintf(stderr, "cannot read %s\n", path);
+        std::exit(2);
+    }
+    std::fclose(f);
+    return v;
+}
+
+#define REQUIRE(c)                                                        \
+    do {                                                                  \
+        if (!(c)) {                                                       \
+            std::fprintf(stderr, "FAILED %s (line %d)\n", #c, __LINE__);  \
+            return 1;                                                     \
+        }                                                                 \
+    } while (0)
+
+int main(int argc, char** argv)
+{
+    if (argc != 5) return 2;
+    const int W = std::atoi(argv[3]), H = std::atoi(argv[4]);
+    std::vector<uint8_t> fa = read_file(argv[1], (size_t)W * H), fb = read_file(argv[2], (size_t)W * H);
+    const int thold = 30, nfeatures = 10000; // main.cc:11
+    try {
+        slamfe::FrontEnd fe(nfeatures, thold, W, H, SLAMFE_MODE_PROVIDED);
+        std::vector<slamfe::KeyPoint> keypoints1, keypoints2;
+        slamfe::Mat8 descriptors1, descriptors2;
+        fe.extractKeyPoints({fa.data(), W, H, W, 1}, keypoints1, descriptors1); // Init.cc:113
+        uint64_t h2 = fe.extractKeyPoints({fb.data(), W, H, W, 1}, keypoints2, descriptors2); // Init.cc:130
+        std::vector<std::vector<slamfe::DMatch>> matches;
+        fe.knnMatch(descriptors1, descriptors2, matches, 2); // Init.cc:131
+
+        // the checker on the same inputs
+        slamfe_params p;
+        slamfe_default_params(&p);
+        p.mode = SLAMFE_MODE_PROVIDED;
+        p.fast_threshold = thold;
+        p.nfeatures = nfeatures;
+        const int cap = W * H / 4 + 16;
+        std::vector<slamfe_keypoint> k1((size_t)cap), k2((size_t)cap);
+        std::vector<uint8_t> d1((size_t)cap * 32), d2((size_t)cap * 32);
+        int n1 = orc_extract(&p, fa.data(), W, H, W, 1, ORC_TRIG_CONTRACT, k1.data(), d1.data(), cap);
+        int n2 = orc_extract(&p, fb.data(), W, H, W, 1, ORC_TRIG_CONTRACT, k2.data(), d2.data(), cap);
+        REQUIRE((int)keypoints1.size() == n1 && (int)keypoints2.size() == n2 && n1 > 100);
+        REQUIRE(std::memcmp(keypoints1.data(), k1.data(), (size_t)n1 * sizeof(slamfe_keypoint)) == 0);
+        REQUIRE(std::memcmp(keypoints2.data(), k2.data(), (size_t)n2 * sizeof(slamfe_keypoint)) == 0);
+        REQUIRE(std::memcmp(descriptors1.data.data(), d1.data(), (size_t)n1 * 32) == 0);
+        REQUIRE(std::memcmp(descriptors2.data.data(), d2.data(), (size_t)n2 * 32) == 0);
+        std::vector<slamfe_match2> om((size_t)n1);
+        orc_match_knn2(d1.data(), n1, d2.data(), n2, 0.75f, om.data());
+
+        // Lowe's ratio test exactly as Init.cc:144-153
+        std::vector<slamfe::DMatch> goodMatches;
+        int oracle_good = 0;
+        for (size_t i = 0; i < matches.size(); ++i) {
+            if (matches[i].size() < 2) break;
+            const float ratio = 0.75;
+            REQUIRE(matches[i][0].trainIdx == om[i].idx0 && matches[i][1].trainIdx == om[i].idx1);
+            REQUIRE(matches[i][0].distance == (float)om[i].d0 && matches[i][1].distance == (float)om[i].d1);
+            REQUIRE(matches[i][0].queryIdx == (int)i && matches[i][0].imgIdx == 0);
+            bool pass = matches[i][0].distance < ratio * matches[i][1].distance;
+            REQUIRE(pass == (om[i].ratio_pass != 0));
+            if (pass) goodMatches.push_back(matches[i][0]);
+            oracle_good += om[i].ratio_pass;
+        }
+        REQUIRE((int)goodMatches.size() == oracle_good && oracle_good > 50);
+
+        // a small map: every third good match becomes a map point made from
+        // frame 2's descriptor row (Init.cc:296), projected near its keypoint
+        std::vector<slamfe::Point2f> rPoints;
+        std::vector<int> rIds;
+        std::vector<uint8_t> pdesc;
+        std::vector<float> uv;
+        int id = 0;
+        for (size_t i = 0; i < goodMatches.size(); i += 3) {
+            int t = goodMatches[i].trainIdx;
+            fe.mapPut(id, descriptors2.ptr(t));
+            rPoints.emplace_back(keypoints2[(size_t)t].pt.x + 1.5f, keypoints2[(size_t)t].pt.y - 2.25f);
+            uv.push_back(rPoints.back().x);
+            uv.push_back(rPoints.back().y);
+            pdesc.insert(pdesc.end(), descriptors2.ptr(t), descriptors2.ptr(t) + 32);
+            rIds.push_back(id++);
+        }
+        std::vector<int> inl;
+        for (auto& m : goodMatches) inl.push_back(m.trainIdx);
+        std::vector<int> got = fe.searchByProjection(h2, inl, rPoints, rIds);
+        std::vector<float> kxy((size_t)n2 * 2);
+        for (int i = 0; i < n2; ++i) {
+            kxy[2 * (size_t)i] = k2[(size_t)i].x;
+            kxy[2 * (size_t)i + 1] = k2[(size_t)i].y;
+        }
+        std::vector<int32_t> want(inl.size());
+        orc_search_by_projection(kxy.data(), d2.data(), inl.data(), (int)inl.size(), uv.data(), pdesc.data(),
+                                 rIds.data(), (int)rIds.size(), 32.f, 128, want.data());
+        int hits = 0;
+        for (size_t i = 0; i < inl.size(); ++i) {
+            REQUIRE(got[i] == want[i]);
+            hits += got[i] >= 0;
+        }
+        REQUIRE(hits >= (int)rIds.size() / 2);
+        std::printf("host adapter ok: %d/%d keypoints, %d good matches, %d map hits\n", n1, n2, oracle_good, hits);
+    } catch (const slamfe::Error& e) {
+        std::fprintf(stderr, "slamfe::Error %d: %s\n", e.code, e.what());
+        return 3;
+    }
+    return 0;
+}
