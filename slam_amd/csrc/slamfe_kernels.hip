@@ -41,6 +41,15 @@ __device__ __forceinline__ int find_level_by_band(const slamfe_dev_geom& g, int 
     return l;
 }
 
+// Frame of a workgroup.  Per-frame kernels are launched on a grid
+// (FX, items, FZ): workgroups are dealt round-robin to the 8 XCDs in linear
+// order (x fastest), so with FX = 8 all workgroups of frame f run on one XCD
+// (f % 8) and share that XCD's L2 -- tile halos, source rows and keypoint
+// neighbourhoods are then fetched from HBM once, not once per XCD.  Batches of
+// fewer than 8 frames use FX = 1 (work items interleaved over the XCDs).
+__device__ __forceinline__ int wg_frame() { return (int)(blockIdx.z * gridDim.x + blockIdx.x); }
+__device__ __forceinline__ int wg_item() { return (int)blockIdx.y; }
+
 __device__ __forceinline__ int reflect101(int i, int n)
 {
     // valid for -n < i < 2n-1, which covers the 3-px reach of the blur
@@ -95,15 +104,16 @@ __device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
     return c.v;
 }
 
-__global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, uint8_t* __restrict__ pyr,
+__global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nframes,
+                                                uint8_t* __restrict__ pyr,
                                                 const uint32_t* __restrict__ taps)
 {
     const slamfe_dev_level& S = g.lv[l - 1];
     const slamfe_dev_level& D = g.lv[l];
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int f = blockIdx.z;
-    if (x >= D.w || y >= D.h) return;
+    const int y = wg_item() * 4 + (threadIdx.x >> 6);
+    const int f = wg_frame();
+    if (f >= nframes || y >= D.h) return;
+    for (int x = (threadIdx.x & 63) * 4; x < D.w; x += 256) {
     const uint8_t* src = pyr + (size_t)f * g.frame_bytes + S.off;
     uint8_t* dst = pyr + (size_t)f * g.frame_bytes + D.off;
     // the tap table is padded with zero entries to a multiple of 4 per level
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, uint8_
     }
     // rows are padded to a multiple of 64 bytes: the dword store stays in the row
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.pitch + x) = out;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -206,8 +217,8 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
 }
 
 __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
-                                                   uint8_t* __restrict__ blur, int thr, int edge,
-                                                   uint32_t* __restrict__ cand,
+                                                   uint8_t* __restrict__ blur, int nframes, int thr,
+                                                   int edge, uint32_t* __restrict__ cand,
                                                    uint32_t* __restrict__ cand_cnt,
                                                    uint32_t* __restrict__ hist)
 {
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
     uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
 
-    const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int t = wg_item(), f = wg_frame(), tid = threadIdx.x;
+    if (f >= nframes) return;
     const int l = find_level_by_tile(g, t);
     const slamfe_dev_level L = g.lv[l];
     const int tl = t - L.tile_base;
@@ -471,10 +483,11 @@ __global__ __launch_bounds__(256) void k_select_count(slamfe_dev_geom g,
                                                       const uint32_t* __restrict__ hist,
                                                       uint32_t* __restrict__ band_cnt,
                                                       uint32_t* __restrict__ level_kept,
-                                                      int32_t* __restrict__ level_cutoff)
+                                                      int32_t* __restrict__ level_cutoff, int nframes)
 {
     __shared__ uint32_t sh[256];
-    const int b = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int b = wg_item(), f = wg_frame(), tid = threadIdx.x;
+    if (f >= nframes) return;
     const int l = find_level_by_band(g, b);
     const slamfe_dev_level L = g.lv[l];
     int cut;
@@ -505,12 +518,13 @@ __global__ __launch_bounds__(256) void k_select_write(
     const uint32_t* __restrict__ band_cnt, const uint32_t* __restrict__ level_kept,
     const int32_t* __restrict__ level_cutoff, int slot_base, int nslots,
     uint32_t* __restrict__ kp_key, uint32_t* __restrict__ kp_level, int32_t* __restrict__ kp_count,
-    int max_kp)
+    int max_kp, int nframes)
 {
     extern __shared__ uint32_t lds[]; // sort buffer: tiles_x_max * 256 entries, power of two
     __shared__ uint32_t red[256];
     __shared__ uint32_t nkeep;
-    const int b = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int b = wg_item(), f = wg_frame(), tid = threadIdx.x;
+    if (f >= nframes) return;
     const int l = find_level_by_band(g, b);
     const slamfe_dev_level L = g.lv[l];
     const int bl = b - L.band_base;
@@ -590,11 +604,12 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
                                                 const uint32_t* __restrict__ kp_key,
                                                 const uint32_t* __restrict__ kp_level,
                                                 const int32_t* __restrict__ kp_count,
-                                                int2* __restrict__ kp_mom, int max_kp)
+                                                int2* __restrict__ kp_mom, int max_kp, int nframes)
 {
-    const int f = blockIdx.y;
+    const int f = wg_frame();
+    if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int idx = wg_item() * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
@@ -646,11 +661,12 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
                                                 const int2* __restrict__ kp_mom,
                                                 slamfe_keypoint* __restrict__ kps,
                                                 float2* __restrict__ kp_rot, int max_kp, int mode,
-                                                int patch_size)
+                                                int patch_size, int nframes)
 {
-    const int f = blockIdx.y;
+    const int f = wg_frame();
+    if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = wg_item() * 256 + threadIdx.x;
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
     if (idx >= n) return;
@@ -697,15 +713,16 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   const uint32_t* __restrict__ kp_level,
                                                   const int32_t* __restrict__ kp_count,
                                                   const float2* __restrict__ kp_rot,
-                                                  uint8_t* __restrict__ desc, int max_kp)
+                                                  uint8_t* __restrict__ desc, int max_kp, int nframes)
 {
     // each wavefront stages the 37-row neighbourhood of its keypoint in LDS with
     // row-contiguous dword loads, then gathers its 512 samples from LDS
     __shared__ uint32_t patch32[4][DP_ROWS * DP_DW];
-    const int f = blockIdx.y;
+    const int f = wg_frame();
+    if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
     const int wv = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 4 + wv;
+    const int idx = wg_item() * 4 + wv;
     const int lane = threadIdx.x & 63;
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
@@ -1171,6 +1188,13 @@ __global__ __launch_bounds__(64) void k_proj_resolve(
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+// grid (FX, items, FZ) of the per-frame kernels; see wg_frame()
+static dim3 frame_grid(int items, int nframes)
+{
+    int fx = nframes >= 8 ? 8 : 1;
+    return dim3((unsigned)fx, (unsigned)items, (unsigned)((nframes + fx - 1) / fx));
+}
+
 #define LAUNCH_CHECK()                          \
     do {                                        \
         hipError_t e_ = hipGetLastError();      \
@@ -1192,8 +1216,8 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
                           const uint32_t* taps)
 {
     for (int l = 1; l < g.nlevels; ++l) {
-        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nframes);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, g, l, pyr, taps);
+        hipLaunchKernelGGL(k_resize, frame_grid((g.lv[l].h + 3) / 4, nframes), dim3(256), 0, s, g, l,
+                           nframes, pyr, taps);
         LAUNCH_CHECK();
     }
     return 0;
@@ -1203,8 +1227,8 @@ int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes
                             uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
                             uint32_t* hist)
 {
-    hipLaunchKernelGGL(k_fast_blur, dim3(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur, thr,
-                       edge, cand, cand_cnt, hist);
+    hipLaunchKernelGGL(k_fast_blur, frame_grid(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur,
+                       nframes, thr, edge, cand, cand_cnt, hist);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1215,12 +1239,12 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
                          size_t sort_lds_bytes)
 {
-    hipLaunchKernelGGL(k_select_count, dim3(g.total_bands, nframes), dim3(256), 0, s, g, cand,
-                       cand_cnt, hist, band_cnt, level_kept, level_cutoff);
+    hipLaunchKernelGGL(k_select_count, frame_grid(g.total_bands, nframes), dim3(256), 0, s, g, cand,
+                       cand_cnt, hist, band_cnt, level_kept, level_cutoff, nframes);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_select_write, dim3(g.total_bands, nframes), dim3(256), sort_lds_bytes, s, g,
-                       cand, cand_cnt, band_cnt, level_kept, level_cutoff, slot_base, nslots, kp_key,
-                       kp_level, kp_count, max_kp);
+    hipLaunchKernelGGL(k_select_write, frame_grid(g.total_bands, nframes), dim3(256), sort_lds_bytes,
+                       s, g, cand, cand_cnt, band_cnt, level_kept, level_cutoff, slot_base, nslots,
+                       kp_key, kp_level, kp_count, max_kp, nframes);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1231,13 +1255,15 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          int max_kp, int mode, int patch_size)
 {
     if (mode == SLAMFE_MODE_ORB) {
-        hipLaunchKernelGGL(k_orient, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, pyr, slot_base,
-                           nslots, kp_key, kp_level, kp_count, reinterpret_cast<int2*>(kp_mom), max_kp);
+        hipLaunchKernelGGL(k_orient, frame_grid((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, pyr,
+                           slot_base, nslots, kp_key, kp_level, kp_count,
+                           reinterpret_cast<int2*>(kp_mom), max_kp, nframes);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_finish, dim3((max_kp + 255) / 256, nframes), dim3(256), 0, s, g, slot_base,
-                       nslots, kp_key, kp_level, kp_count, reinterpret_cast<const int2*>(kp_mom), kps,
-                       reinterpret_cast<float2*>(kp_rot), max_kp, mode, patch_size);
+    hipLaunchKernelGGL(k_finish, frame_grid((max_kp + 255) / 256, nframes), dim3(256), 0, s, g,
+                       slot_base, nslots, kp_key, kp_level, kp_count,
+                       reinterpret_cast<const int2*>(kp_mom), kps, reinterpret_cast<float2*>(kp_rot),
+                       max_kp, mode, patch_size, nframes);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1247,9 +1273,9 @@ int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes,
                            const uint32_t* kp_level, const int32_t* kp_count,
                            const float* kp_rot, uint8_t* desc, int max_kp)
 {
-    hipLaunchKernelGGL(k_describe, dim3((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, blur,
+    hipLaunchKernelGGL(k_describe, frame_grid((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, blur,
                        slot_base, nslots, kp_key, kp_level, kp_count,
-                       reinterpret_cast<const float2*>(kp_rot), desc, max_kp);
+                       reinterpret_cast<const float2*>(kp_rot), desc, max_kp, nframes);
     LAUNCH_CHECK();
     return 0;
 }
