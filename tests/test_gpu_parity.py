@@ -271,3 +271,68 @@ def test_match_resident_batch(fe_orb):
         g = got[i].reshape(-1).view(abi.MATCH2_DTYPE)[:len(want)]
         for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
             assert np.array_equal(g[name], want[name]), (i, name)
+
+
+# ------------------------------------------------- BASELINE configs at full size
+def _full_size_case(w, h, nfeat, seed, batch=1):
+    from slam_amd.frontend import FrontEnd
+    img = synth.textured_canvas(w, h, seed)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=nfeat, max_width=w, max_height=h,
+                  max_batch=batch) as fe:
+        f = fe.extract_keypoints(img)
+        p = oracle_params(fe)
+        kps, desc = O.extract(p, img)
+        assert len(kps) >= nfeat
+        assert_frame_equal(f, kps, desc)
+        # every level's quota is saturated on the benchmark texture
+        assert np.all(np.bincount(kps["octave"], minlength=8) >= O.level_quotas(nfeat))
+    return f
+
+
+def test_config3_1920x1080_5000_features():
+    _full_size_case(1920, 1080, 5000, 100)
+
+
+def test_config5_3840x2160_10000_features():
+    # 60 tiles per band: the selection sort needs the >64 KiB dynamic-LDS path
+    _full_size_case(3840, 2160, 10000, 5)
+
+
+def test_config2_kitti_stream_with_20k_map():
+    from slam_amd.frontend import FrontEnd
+    frames = synth.frame_stream(1241, 376, 2, seed=9)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=3000, max_width=1241,
+                  max_height=376, max_batch=2, map_capacity=20000) as fe:
+        f0, f1 = fe.extract_batch(list(frames))
+        p = oracle_params(fe)
+        for img, f in zip(frames, (f0, f1)):
+            kps, desc = O.extract(p, img)
+            assert len(kps) >= 3000
+            assert_frame_equal(f, kps, desc)
+        m = fe.knn_match_frames(f0, f1)
+        want = O.match_knn2(f0.descriptors, f1.descriptors)
+        for name in ("idx0", "idx1", "d0", "d1", "ratio_pass"):
+            assert np.array_equal(m[name], want[name]), name
+        uv, pdesc = synth.local_map(f1.descriptors, f1.pt, 20000, 1241, 376, seed=11)
+        ids = np.arange(20000, dtype=np.int32)
+        fe.map_put(ids, pdesc)
+        inl = m["idx0"][m["ratio_pass"] == 1].astype(np.int32)  # goodMatches[i].trainIdx
+        got = fe.search_by_projection(f1, inl, uv, ids)
+        assert np.array_equal(got, O.search_by_projection(f1.pt, f1.descriptors, inl, uv, pdesc, ids))
+        assert (got >= 0).sum() > 500
+
+
+def test_extract_all_dark_and_all_bright_frames(fe_orb):
+    for v in (0, 255):
+        assert len(fe_orb.extract_keypoints(np.full((480, 640), v, np.uint8))) == 0
+
+
+def test_extract_checkerboard_ties(fe_orb):
+    # a regular pattern produces many equal scores: NMS ties and a cut-off bin
+    # holding far more keypoints than the quota
+    yy, xx = np.mgrid[0:480, 0:640]
+    img = (((xx // 8) + (yy // 8)) % 2 * 200 + 20).astype(np.uint8)
+    img[::7, ::5] += 9
+    f = fe_orb.extract_keypoints(img) if True else None
+    kps, desc = O.extract(oracle_params(fe_orb), img)
+    assert_frame_equal(f, kps, desc)
