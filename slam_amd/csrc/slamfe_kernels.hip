@@ -178,9 +178,12 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
 //                 (3.5 VALU ops per output), 16-bit sums to LDS
 //         cols:   v_dot2_u32_u16 per tap, round, saturate, 4 pixels per store
 // ---------------------------------------------------------------------------
-#define FL_W (TW + 8)          /* 72 bytes = 18 dwords per LDS tile row */
+#define FL_W (TW + 32)         /* LDS tile row: image columns x0-16 .. x0+79, six 16-byte pieces */
 #define FL_WD (FL_W / 4)
-#define FL_H (TH + 8)          /* 24 rows */
+#define FL_X0 12               /* byte column of image column x0-4 (the first one that is used) */
+#define FL_H (TH + 8)          /* 24 rows: y0-4 .. y0+19 */
+#define FB_COLS (TW + 8)       /* used columns: x0-4 .. x0+67 = 18 dwords */
+#define FB_COLD (FB_COLS / 4)
 #define FS_W (TW + 2)          /* score tile: 66 x 18 */
 #define FS_H (TH + 2)
 #define FS_N (FS_W * FS_H)     /* 1188 */
@@ -243,24 +246,41 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         nlist = 0;
         npos = 0;
     }
-    // ---- tile load: 24 rows x 18 dwords, image (y0-4.., x0-4..)
-    for (int i = tid; i < FL_H * FL_WD; i += 256) {
-        int ly = i / FL_WD, dx = i - ly * FL_WD;
+    // ---- tile load: 24 rows x six aligned 16-byte pieces (columns x0-16 .. x0+79;
+    // columns x0-4 .. x0+67 are used).  Rows reflect at the top / bottom border by
+    // index; pieces outside the row are zero, bytes past w inside the row's
+    // padding are don't-care until the fix-up below.
+    if (tid < FL_H * 6) {
+        int ly = tid / 6, pc = tid - ly * 6;
         int gy = reflect101(y0 - 4 + ly, L.h);
-        int gx = x0 - 4 + 4 * dx;
-        const uint8_t* row = img + (size_t)gy * L.pitch;
-        uint32_t v;
-        if (gx >= 0 && gx + 3 < L.w) {
-            v = *reinterpret_cast<const uint32_t*>(row + gx);
-        } else {
-            v = (uint32_t)row[reflect101(gx, L.w)] | ((uint32_t)row[reflect101(gx + 1, L.w)] << 8) |
-                ((uint32_t)row[reflect101(gx + 2, L.w)] << 16) |
-                ((uint32_t)row[reflect101(gx + 3, L.w)] << 24);
-        }
-        tile32[i] = v;
+        int gx = x0 - 16 + 16 * pc;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gx >= 0 && gx < L.pitch)
+            v = *reinterpret_cast<const uint4*>(img + (size_t)gy * L.pitch + gx);
+        *reinterpret_cast<uint4*>(&tile32[ly * FL_WD + 4 * pc]) = v;
     }
     for (int i = tid; i < (FS_N + 3) / 4; i += 256) sc32[i] = 0;
     __syncthreads();
+    // REFLECT_101 at the left / right image border (the blur reads 3 px across
+    // it): copy the mirrored bytes inside LDS.  Only border tiles take this.
+    {
+        const bool left = x0 == 0, right = x0 + TW + 3 >= L.w;
+        if (left || right) { // uniform per workgroup
+            uint8_t* tb = reinterpret_cast<uint8_t*>(tile32);
+            if (tid < FL_H * 8) {
+                int ly = tid >> 3, k = tid & 7; // k 0..2: left side, 4..6: right side
+                if (left && k < 3) {
+                    // column -(k+1) <- column k+1
+                    tb[ly * FL_W + FL_X0 + 4 - (k + 1)] = tb[ly * FL_W + FL_X0 + 4 + (k + 1)];
+                } else if (right && k >= 4 && k < 7) {
+                    int x = L.w + (k - 4); // <- column 2(w-1) - x
+                    int lx = x - (x0 - 16), sx = 2 * (L.w - 1) - x - (x0 - 16);
+                    if (lx < FL_W && sx >= 0) tb[ly * FL_W + lx] = tb[ly * FL_W + sx];
+                }
+            }
+            __syncthreads();
+        }
+    }
 
     // ---- FAST pass B: pretest on the tile + 1-px ring, 4 pixels per task.
     // Task = (score row sy of 18, dword column m of 18); its pixels are LDS
@@ -274,13 +294,11 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         // tiles that lie entirely in the discarded border band skip FAST
         const bool any_fast = x0 + TW + 1 > blo && x0 - 1 < L.w - blo && y0 + TH + 1 > blo &&
                               y0 - 1 < L.h - blo;
-        for (int i = tid; any_fast && i < FS_H * FL_WD; i += 256) {
-            int sy = i / FL_WD, m = i - sy * FL_WD;
+        for (int i = tid; any_fast && i < FS_H * FB_COLD; i += 256) {
+            int sy = i / FB_COLD, m = i - sy * FB_COLD;
             int ly = sy + 3;
-            const uint32_t* row = &tile32[ly * FL_WD + m];
-            uint32_t C = row[0];
-            uint32_t Cp = m > 0 ? row[-1] : 0u;
-            uint32_t Cn = m < FL_WD - 1 ? row[1] : 0u;
+            const uint32_t* row = &tile32[ly * FL_WD + FL_X0 / 4 + m];
+            uint32_t C = row[0], Cp = row[-1], Cn = row[1];
             uint32_t U = row[-3 * FL_WD], D = row[3 * FL_WD];
             uint32_t L3 = __builtin_amdgcn_alignbyte(C, Cp, 1); // pixels at x-3
             uint32_t R3 = __builtin_amdgcn_alignbyte(Cn, C, 3); // pixels at x+3
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         const uint32_t KB = 49u | (34u << 8) | (18u << 16);               // taps 4..6, 0
         for (int i = tid; i < BR_H * 16; i += 256) {
             int r = i >> 4, k = i & 15;
-            const uint32_t* p = &tile32[(r + 1) * FL_WD + k]; // bytes lx = 4k .. 4k+11
+            const uint32_t* p = &tile32[(r + 1) * FL_WD + FL_X0 / 4 + k]; // columns x0-4+4k .. +11
             uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
             // output c = 4k+j reads bytes (j+1 .. j+7) of the 12-byte window
             uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0, false);
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     for (uint32_t k = tid; k < np; k += 256) {
         int i = pos[k];
         int sy = i / FS_W, sx = i - sy * FS_W;
-        sc[i] = (uint8_t)fast_score_lds(&tile[(sy + 3) * FL_W + sx + 3], thr);
+        sc[i] = (uint8_t)fast_score_lds(&tile[(sy + 3) * FL_W + FL_X0 + sx + 3], thr);
     }
 
     // ---- blur column pass: task = (row r of 16, group k of 16) -> 4 pixels
