@@ -280,23 +280,34 @@ static inline int reflect101(int i, int n)
 
 void orc_gaussian_blur7(const uint8_t* src, int w, int h, int stride, uint8_t* dst, int dstride)
 {
+    /* row pass into 32-bit sums (<= 257 * 255), then column pass; borders by
+     * REFLECT_101 index, the interior without index arithmetic */
     int* rows = (int*)malloc(sizeof(int) * (size_t)w * h);
     for (int y = 0; y < h; ++y) {
         const uint8_t* s = src + (size_t)y * stride;
+        int* r = rows + (size_t)y * w;
         for (int x = 0; x < w; ++x) {
-            int acc = 0;
-            for (int k = -3; k <= 3; ++k) acc += k_gauss[k + 3] * s[reflect101(x + k, w)];
-            rows[(size_t)y * w + x] = acc;
+            if (x >= 3 && x < w - 3) {
+                r[x] = k_gauss[0] * (s[x - 3] + s[x + 3]) + k_gauss[1] * (s[x - 2] + s[x + 2]) +
+                       k_gauss[2] * (s[x - 1] + s[x + 1]) + k_gauss[3] * s[x];
+            } else {
+                int acc = 0;
+                for (int k = -3; k <= 3; ++k) acc += k_gauss[k + 3] * s[reflect101(x + k, w)];
+                r[x] = acc;
+            }
         }
     }
-    for (int y = 0; y < h; ++y)
+    for (int y = 0; y < h; ++y) {
+        const int* r[7];
+        for (int k = -3; k <= 3; ++k) r[k + 3] = rows + (size_t)reflect101(y + k, h) * w;
+        uint8_t* d = dst + (size_t)y * dstride;
         for (int x = 0; x < w; ++x) {
-            int acc = 0;
-            for (int k = -3; k <= 3; ++k)
-                acc += k_gauss[k + 3] * rows[(size_t)reflect101(y + k, h) * w + x];
+            int acc = k_gauss[0] * (r[0][x] + r[6][x]) + k_gauss[1] * (r[1][x] + r[5][x]) +
+                      k_gauss[2] * (r[2][x] + r[4][x]) + k_gauss[3] * r[3][x];
             int v = (acc + (1 << 15)) >> 16;
-            dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
+            d[x] = (uint8_t)(v > 255 ? 255 : v);
         }
+    }
     free(rows);
 }
 
@@ -462,7 +473,7 @@ int orc_extract(const slamfe_params* p, const uint8_t* img, int w, int h, int st
 
 /* --------------------------------------------------------------- matching */
 
-int orc_hamming256(const uint8_t* a, const uint8_t* b)
+static inline int hamming256(const uint8_t* a, const uint8_t* b)
 {
     uint64_t x[4], y[4];
     memcpy(x, a, 32);
@@ -470,6 +481,8 @@ int orc_hamming256(const uint8_t* a, const uint8_t* b)
     return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
            __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
 }
+
+int orc_hamming256(const uint8_t* a, const uint8_t* b) { return hamming256(a, b); }
 
 /* BFMatcher(NORM_HAMMING, crossCheck=false)::knnMatch, k = 2 (Init.cc:66,
  * Init.cc:131): scan train rows in ascending order; a candidate enters the
@@ -483,7 +496,7 @@ void orc_match_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt, 
         int d0 = INT_MAX, d1 = INT_MAX, i0 = -1, i1 = -1;
         const uint8_t* q = query + (size_t)i * 32;
         for (int j = 0; j < nt; ++j) {
-            int d = orc_hamming256(q, train + (size_t)j * 32);
+            int d = hamming256(q, train + (size_t)j * 32);
             if (d < d1) {
                 if (d < d0) {
                     d1 = d0; i1 = i0;
@@ -531,7 +544,7 @@ void orc_search_by_projection(const float* kp_xy, const uint8_t* frame_desc, con
         double minDistance = DBL_MAX;
         for (int j = 0; j < nlive; ++j) {
             int k = live[j];
-            double distance = (double)orc_hamming256(point_desc + (size_t)k * 32,
+            double distance = (double)hamming256(point_desc + (size_t)k * 32,
                                                      frame_desc + (size_t)idx * 32);
             float e = euclid_ref(uv[2 * k], uv[2 * k + 1], kp_xy[2 * idx], kp_xy[2 * idx + 1]);
             if (distance <= max_hamming && e <= radius) {
