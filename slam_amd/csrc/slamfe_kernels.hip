@@ -62,25 +62,42 @@ __device__ __forceinline__ int reflect101(int i, int n)
 // K1  frame ingest: gray copy or BGR -> gray into pyramid level 0
 //     (cv::cvtColor(frame, frame, COLOR_BGR2GRAY), Init.cc:75)
 // ---------------------------------------------------------------------------
+// A lane produces 16 pixels (one 16-byte store; rows are padded to 64 bytes, so
+// the store may run past w inside the row).  Gray rows that are 16-byte aligned
+// are copied with one 16-byte load; everything else goes pixel by pixel.
 __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ in, int w, int h,
                                                 int stride, size_t frame_stride, int channels,
                                                 uint8_t* __restrict__ pyr, uint32_t frame_bytes,
-                                                int pitch)
+                                                int pitch, int aligned16)
 {
-    int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    int f = blockIdx.z;
-    if (x >= w) return;
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.z;
+    if (x >= w || y >= h) return;
     const uint8_t* src = in + (size_t)f * frame_stride + (size_t)y * stride;
-    uint8_t v;
-    if (channels == 3) {
-        int b = src[3 * x], gg = src[3 * x + 1], r = src[3 * x + 2];
-        v = (uint8_t)((b * SLAMFE_B2Y + gg * SLAMFE_G2Y + r * SLAMFE_R2Y +
-                       (1 << (SLAMFE_GRAY_SHIFT - 1))) >> SLAMFE_GRAY_SHIFT);
+    uint4 o;
+    if (channels == 1 && aligned16 && x + 16 <= w) {
+        o = *reinterpret_cast<const uint4*>(src + x);
     } else {
-        v = src[x];
+        uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int xx = x + k;
+            uint32_t v = 0;
+            if (xx < w) {
+                if (channels == 3) {
+                    int b = src[3 * xx], gg = src[3 * xx + 1], r = src[3 * xx + 2];
+                    v = (uint32_t)((b * SLAMFE_B2Y + gg * SLAMFE_G2Y + r * SLAMFE_R2Y +
+                                    (1 << (SLAMFE_GRAY_SHIFT - 1))) >> SLAMFE_GRAY_SHIFT);
+                } else {
+                    v = src[xx];
+                }
+            }
+            wd[k >> 2] |= v << (8 * (k & 3));
+        }
+        o = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
-    pyr[(size_t)f * frame_bytes + (size_t)y * pitch + x] = v;
+    *reinterpret_cast<uint4*>(pyr + (size_t)f * frame_bytes + (size_t)y * pitch + x) = o;
 }
 
 // ---------------------------------------------------------------------------
@@ -1223,9 +1240,10 @@ int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int s
                          size_t frame_stride, int channels, int nframes, uint8_t* pyr,
                          uint32_t frame_bytes, int pitch)
 {
-    dim3 grid((w + 255) / 256, h, nframes);
+    dim3 grid((w + 1023) / 1024, (h + 3) / 4, nframes);
+    int aligned16 = ((uintptr_t)d_in % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;
     hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, d_in, w, h, stride, frame_stride, channels,
-                       pyr, frame_bytes, pitch);
+                       pyr, frame_bytes, pitch, aligned16);
     LAUNCH_CHECK();
     return 0;
 }
