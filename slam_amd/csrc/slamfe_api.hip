@@ -7,7 +7,7 @@
 //                                               level l at lv[l].off, rows of
 //                                               lv[l].pitch bytes (64-B aligned)
 //   cand            [max_batch][tiles][256] u32 FAST survivors per 64x16 tile
-//   hist            [max_batch][levels][256]    score histograms
+//   band_hist       [max_batch][bands][256]     score histogram of every tile row
 //   frame slots     [frame_slots][max_kp]       keys, levels, cv::KeyPoint
 //                                               records, 32-byte descriptor rows
 //   map_desc        [map_capacity][32]          mirror of Point::desc
@@ -53,7 +53,7 @@ struct slamfe_ctx {
 
     uint8_t *pyr = nullptr, *blur = nullptr, *in_stage = nullptr;
     uint32_t* taps = nullptr;
-    uint32_t *cand = nullptr, *cand_cnt = nullptr, *hist = nullptr, *band_cnt = nullptr,
+    uint32_t *cand = nullptr, *cand_cnt = nullptr, *band_hist = nullptr, *band_off = nullptr,
              *level_kept = nullptr;
     int32_t* level_cutoff = nullptr;
 
@@ -271,13 +271,12 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     }
     c->next_seq += (uint64_t)n;
 
-    HIPCHK(c, hipMemsetAsync(c->hist, 0, (size_t)n * g.nlevels * 256 * sizeof(uint32_t), s));
     KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
                                  g.frame_bytes, g.lv[0].pitch));
     KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
     KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
-                                    c->p.edge_threshold, c->cand, c->cand_cnt, c->hist));
-    KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->hist, c->band_cnt, c->level_kept,
+                                    c->p.edge_threshold, c->cand, c->cand_cnt));
+    KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->band_hist, c->band_off, c->level_kept,
                                  c->level_cutoff, slot_base, c->nslots, c->kp_key, c->kp_level,
                                  c->kp_count, c->max_kp, c->sort_lds));
     KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
@@ -344,8 +343,8 @@ void slamfe_destroy(slamfe_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->p.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->pyr, c->blur, c->in_stage, c->taps, c->cand, c->cand_cnt, c->hist,
-                    c->band_cnt, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
+    void* bufs[] = {c->pyr, c->blur, c->in_stage, c->taps, c->cand, c->cand_cnt, c->band_hist,
+                    c->band_off, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
                     c->kp_count, c->kps, c->desc, c->kp_mom, c->kp_rot, c->match_out, c->map_desc, c->match_part.p,
                     c->match_q.p, c->match_t.p, c->match_o.p, c->pj_idx.p, c->pj_uv.p,
                     c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p};
@@ -414,8 +413,8 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     HIPCHK(c, hipMalloc(&c->taps, c->cap_taps * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->cand, B * c->cap_tiles * SLAMFE_TILE_CAND * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->cand_cnt, B * c->cap_tiles * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&c->hist, B * SLAMFE_MAX_LEVELS * 256 * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&c->band_cnt, B * c->cap_bands * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->band_hist, B * c->cap_bands * 256 * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->band_off, B * c->cap_bands * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->level_kept, B * SLAMFE_MAX_LEVELS * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->level_cutoff, B * SLAMFE_MAX_LEVELS * sizeof(int32_t)));
     const size_t S = (size_t)c->nslots, K = (size_t)c->max_kp;
@@ -730,13 +729,11 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
             KCHK(c, slamfe_launch_pyramid(s, g, nframes, c->pyr, c->taps));
             break;
         case SLAMFE_STAGE_FAST:
-            // the histograms are zeroed before every FAST pass, as in the real pipeline
-            HIPCHK(c, hipMemsetAsync(c->hist, 0, (size_t)nframes * g.nlevels * 256 * sizeof(uint32_t), s));
             KCHK(c, slamfe_launch_fast_blur(s, g, nframes, c->pyr, c->blur, c->p.fast_threshold,
-                                            c->p.edge_threshold, c->cand, c->cand_cnt, c->hist));
+                                            c->p.edge_threshold, c->cand, c->cand_cnt));
             break;
         case SLAMFE_STAGE_SELECT:
-            KCHK(c, slamfe_launch_select(s, g, nframes, c->cand, c->cand_cnt, c->hist, c->band_cnt,
+            KCHK(c, slamfe_launch_select(s, g, nframes, c->cand, c->cand_cnt, c->band_hist, c->band_off,
                                          c->level_kept, c->level_cutoff, slot_base, c->nslots,
                                          c->kp_key, c->kp_level, c->kp_count, c->max_kp, c->sort_lds));
             break;

@@ -15,10 +15,9 @@ int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int s
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
                           const uint32_t* taps);
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
-                            uint32_t* hist);
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt);
 int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,
-                         const uint32_t* cand_cnt, const uint32_t* hist, uint32_t* band_cnt,
+                         const uint32_t* cand_cnt, uint32_t* band_hist, uint32_t* band_off,
                          uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
                          size_t sort_lds_bytes);

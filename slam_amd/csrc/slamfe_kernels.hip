@@ -239,8 +239,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
 __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
                                                    uint8_t* __restrict__ blur, int nframes, int thr,
                                                    int edge, uint32_t* __restrict__ cand,
-                                                   uint32_t* __restrict__ cand_cnt,
-                                                   uint32_t* __restrict__ hist)
+                                                   uint32_t* __restrict__ cand_cnt)
 {
     __shared__ uint32_t tile32[FL_H * FL_WD];
     __shared__ uint32_t sc32[(FS_N + 3) / 4];
@@ -444,7 +443,6 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     __syncthreads();
 
     // ---- FAST pass D: NMS of the survivors, border filter, emission
-    uint32_t* hl = hist + ((size_t)f * g.nlevels + l) * 256;
     for (uint32_t k = tid; k < np; k += 256) {
         int i = pos[k];
         int s = sc[i];
@@ -457,7 +455,6 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             if (s > m && gx >= edge && gx < L.w - edge && gy >= edge && gy < L.h - edge) {
                 uint32_t q = atomicAdd(&nlist, 1u);
                 list[q] = SLAMFE_KEY(gx, gy, s);
-                atomicAdd(&hl[s], 1u);
             }
         }
     }
@@ -472,91 +469,107 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
 // K4  keypoint selection (KeyPointsFilter::retainBest inside cv::ORB) and
 //     ordered compaction.
 //
-// Scores are integers below 256, so the retain-best cut-off is read from the
-// level's histogram: cut = the quota-th best score; every candidate with
-// score >= cut is kept (ties included).  Pass 1 counts kept candidates per
-// tile row ("band"); pass 2 turns the counts into offsets, sorts each band's
-// kept candidates by (y, x) in LDS and writes them in (level, y, x) order.
+// Scores are integers below 256, so the retain-best cut-off is read from a
+// histogram: cut = the quota-th best score of the level; every candidate with
+// score >= cut is kept (ties included).
+//   k_band_hist   one workgroup per tile row ("band"): LDS histogram of the
+//                 band's candidate scores, stored whole (no global atomics: a
+//                 level-wide histogram updated per keypoint serialises on a
+//                 few hot bins)
+//   k_level_cut   one workgroup per level: sum the band histograms, find the
+//                 cut, the kept total and every band's output offset
+//   k_select_write  per band: gather the kept keys, bitonic sort in LDS by
+//                 (y, x), write at the band's offset -> (level, y, x) order
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void level_cut(const uint32_t* __restrict__ hl, int quota, uint32_t* sh,
-                                          int* cut_out, uint32_t* kept_out)
+__global__ __launch_bounds__(256) void k_band_hist(slamfe_dev_geom g,
+                                                   const uint32_t* __restrict__ cand,
+                                                   const uint32_t* __restrict__ cand_cnt,
+                                                   uint32_t* __restrict__ band_hist, int nframes)
 {
-    // sh: 256 uint32 of LDS.  Inclusive suffix sum of the histogram.
-    const int tid = threadIdx.x;
-    sh[tid] = hl[tid];
+    __shared__ uint32_t h[256];
+    const int b = wg_item(), f = wg_frame(), tid = threadIdx.x;
+    if (f >= nframes) return;
+    const int l = find_level_by_band(g, b);
+    const slamfe_dev_level L = g.lv[l];
+    const int bl = b - L.band_base;
+    h[tid] = 0;
     __syncthreads();
+    size_t t0 = (size_t)f * g.total_tiles + L.tile_base + (size_t)bl * L.tiles_x;
+    for (int tx = 0; tx < L.tiles_x; ++tx) {
+        uint32_t n = cand_cnt[t0 + tx];
+        if (tid < n) atomicAdd(&h[SLAMFE_KEY_S(cand[(t0 + tx) * SLAMFE_TILE_CAND + tid])], 1u);
+    }
+    __syncthreads();
+    band_hist[((size_t)f * g.total_bands + b) * 256 + tid] = h[tid];
+}
+
+__global__ __launch_bounds__(256) void k_level_cut(slamfe_dev_geom g,
+                                                   const uint32_t* __restrict__ band_hist,
+                                                   uint32_t* __restrict__ band_off,
+                                                   uint32_t* __restrict__ level_kept,
+                                                   int32_t* __restrict__ level_cutoff, int nframes)
+{
+    __shared__ uint32_t sh[256];
+    const int l = wg_item(), f = wg_frame(), tid = threadIdx.x;
+    if (f >= nframes) return;
+    const slamfe_dev_level L = g.lv[l];
+    const int nb = L.tiles_y;
+    const uint32_t* bh = band_hist + ((size_t)f * g.total_bands + L.band_base) * 256;
+    uint32_t mine = 0;
+    for (int b = 0; b < nb; ++b) mine += bh[(size_t)b * 256 + tid];
+    sh[tid] = mine;
+    __syncthreads();
+    // inclusive suffix sum: sh[s] = candidates of the level with score >= s
     for (int ofs = 1; ofs < 256; ofs <<= 1) {
         uint32_t v = sh[tid] + (tid + ofs < 256 ? sh[tid + ofs] : 0u);
         __syncthreads();
         sh[tid] = v;
         __syncthreads();
     }
-    // suffix[s] = candidates with score >= s (non-increasing in s)
-    uint32_t total = sh[0];
+    const uint32_t total = sh[0];
     int cut;
     uint32_t kept;
-    if (total <= (uint32_t)quota) {
+    if (total <= (uint32_t)L.quota) {
         cut = 0;
         kept = total;
-    } else if (quota <= 0) {
+    } else if (L.quota <= 0) {
         cut = 256;
         kept = 0;
     } else {
-        // largest s with suffix[s] >= quota = number of s with suffix[s] >= quota, minus 1
-        int c = __syncthreads_count(sh[tid] >= (uint32_t)quota);
+        // largest s with suffix[s] >= quota = (number of s with suffix[s] >= quota) - 1
+        int c = __syncthreads_count(sh[tid] >= (uint32_t)L.quota);
         cut = c - 1;
         kept = sh[cut];
     }
     __syncthreads();
-    *cut_out = cut;
-    *kept_out = kept;
-}
-
-__global__ __launch_bounds__(256) void k_select_count(slamfe_dev_geom g,
-                                                      const uint32_t* __restrict__ cand,
-                                                      const uint32_t* __restrict__ cand_cnt,
-                                                      const uint32_t* __restrict__ hist,
-                                                      uint32_t* __restrict__ band_cnt,
-                                                      uint32_t* __restrict__ level_kept,
-                                                      int32_t* __restrict__ level_cutoff, int nframes)
-{
-    __shared__ uint32_t sh[256];
-    const int b = wg_item(), f = wg_frame(), tid = threadIdx.x;
-    if (f >= nframes) return;
-    const int l = find_level_by_band(g, b);
-    const slamfe_dev_level L = g.lv[l];
-    int cut;
-    uint32_t kept;
-    level_cut(hist + ((size_t)f * g.nlevels + l) * 256, L.quota, sh, &cut, &kept);
-    const int bl = b - L.band_base;
-    if (bl == 0 && tid == 0) {
+    if (tid == 0) {
         level_kept[f * SLAMFE_MAX_LEVELS + l] = kept;
         level_cutoff[f * SLAMFE_MAX_LEVELS + l] = cut;
     }
-    size_t t0 = (size_t)f * g.total_tiles + L.tile_base + (size_t)bl * L.tiles_x;
-    int cnt = 0;
-    for (int tx = 0; tx < L.tiles_x; ++tx) {
-        uint32_t n = cand_cnt[t0 + tx];
-        if (tid < n) cnt += (int)SLAMFE_KEY_S(cand[(t0 + tx) * SLAMFE_TILE_CAND + tid]) >= cut;
-    }
-    sh[tid] = (uint32_t)cnt;
+    // kept count of band `tid` (a level has at most 4096 / 16 = 256 bands), then
+    // the exclusive prefix = the band's offset inside the level
+    uint32_t c = 0;
+    if (tid < nb)
+        for (int s = cut; s < 256; ++s) c += bh[(size_t)tid * 256 + s];
+    sh[tid] = c;
     __syncthreads();
-    for (int ofs = 128; ofs > 0; ofs >>= 1) {
-        if (tid < ofs) sh[tid] += sh[tid + ofs];
+    for (int ofs = 1; ofs < 256; ofs <<= 1) {
+        uint32_t v = sh[tid] + (tid >= ofs ? sh[tid - ofs] : 0u);
+        __syncthreads();
+        sh[tid] = v;
         __syncthreads();
     }
-    if (tid == 0) band_cnt[(size_t)f * g.total_bands + b] = sh[0];
+    if (tid < nb) band_off[(size_t)f * g.total_bands + L.band_base + tid] = sh[tid] - c;
 }
 
 __global__ __launch_bounds__(256) void k_select_write(
     slamfe_dev_geom g, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
-    const uint32_t* __restrict__ band_cnt, const uint32_t* __restrict__ level_kept,
+    const uint32_t* __restrict__ band_off, const uint32_t* __restrict__ level_kept,
     const int32_t* __restrict__ level_cutoff, int slot_base, int nslots,
     uint32_t* __restrict__ kp_key, uint32_t* __restrict__ kp_level, int32_t* __restrict__ kp_count,
     int max_kp, int nframes)
 {
     extern __shared__ uint32_t lds[]; // sort buffer: tiles_x_max * 256 entries, power of two
-    __shared__ uint32_t red[256];
     __shared__ uint32_t nkeep;
     const int b = wg_item(), f = wg_frame(), tid = threadIdx.x;
     if (f >= nframes) return;
@@ -566,18 +579,10 @@ __global__ __launch_bounds__(256) void k_select_write(
     const int cut = level_cutoff[f * SLAMFE_MAX_LEVELS + l];
     const int slot = (slot_base + f) % nslots;
 
-    // offset = kept keypoints of lower levels + kept of earlier bands of this level
-    uint32_t part = 0;
-    if (tid < l) part = level_kept[f * SLAMFE_MAX_LEVELS + tid];
-    for (int i = tid; i < bl; i += 256) part += band_cnt[(size_t)f * g.total_bands + L.band_base + i];
-    red[tid] = part;
+    // offset = kept keypoints of lower levels + the band's offset inside the level
+    uint32_t offset = band_off[(size_t)f * g.total_bands + b];
+    for (int i = 0; i < l; ++i) offset += level_kept[f * SLAMFE_MAX_LEVELS + i];
     if (tid == 0) nkeep = 0;
-    __syncthreads();
-    for (int ofs = 128; ofs > 0; ofs >>= 1) {
-        if (tid < ofs) red[tid] += red[tid + ofs];
-        __syncthreads();
-    }
-    const uint32_t offset = red[0];
     if (b == 0 && tid == 0) {
         uint32_t tot = 0;
         for (int i = 0; i < g.nlevels; ++i) tot += level_kept[f * SLAMFE_MAX_LEVELS + i];
@@ -1260,26 +1265,28 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
 }
 
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
-                            uint32_t* hist)
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt)
 {
     hipLaunchKernelGGL(k_fast_blur, frame_grid(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur,
-                       nframes, thr, edge, cand, cand_cnt, hist);
+                       nframes, thr, edge, cand, cand_cnt);
     LAUNCH_CHECK();
     return 0;
 }
 
 int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,
-                         const uint32_t* cand_cnt, const uint32_t* hist, uint32_t* band_cnt,
+                         const uint32_t* cand_cnt, uint32_t* band_hist, uint32_t* band_off,
                          uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
                          size_t sort_lds_bytes)
 {
-    hipLaunchKernelGGL(k_select_count, frame_grid(g.total_bands, nframes), dim3(256), 0, s, g, cand,
-                       cand_cnt, hist, band_cnt, level_kept, level_cutoff, nframes);
+    hipLaunchKernelGGL(k_band_hist, frame_grid(g.total_bands, nframes), dim3(256), 0, s, g, cand,
+                       cand_cnt, band_hist, nframes);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_level_cut, frame_grid(g.nlevels, nframes), dim3(256), 0, s, g, band_hist,
+                       band_off, level_kept, level_cutoff, nframes);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_select_write, frame_grid(g.total_bands, nframes), dim3(256), sort_lds_bytes,
-                       s, g, cand, cand_cnt, band_cnt, level_kept, level_cutoff, slot_base, nslots,
+                       s, g, cand, cand_cnt, band_off, level_kept, level_cutoff, slot_base, nslots,
                        kp_key, kp_level, kp_count, max_kp, nframes);
     LAUNCH_CHECK();
     return 0;
