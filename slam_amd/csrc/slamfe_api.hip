@@ -52,6 +52,12 @@ struct slamfe_ctx {
     size_t cap_taps = 0;
 
     uint8_t *pyr = nullptr, *blur = nullptr, *in_stage = nullptr;
+    // pinned host staging for the host-pointer calls (allocated on first use):
+    // pageable hipMemcpy costs milliseconds per call, pinned copies microseconds
+    uint8_t *h_in = nullptr, *h_out = nullptr;
+    int32_t* h_cnt = nullptr; // allocated at creation
+    uint8_t* h_pin = nullptr;  // general pinned bounce buffer (grows)
+    size_t h_pin_bytes = 0;
     uint32_t* taps = nullptr;
     uint32_t *cand = nullptr, *cand_cnt = nullptr, *band_hist = nullptr, *band_off = nullptr,
              *level_kept = nullptr;
@@ -119,6 +125,22 @@ int grow(slamfe_ctx* c, Scratch& s, size_t bytes)
     s.bytes = want;
     return SLAMFE_OK;
 }
+
+// Pinned bounce buffer of at least `bytes` for the host-pointer calls.
+int pin_reserve(slamfe_ctx* c, size_t bytes)
+{
+    if (bytes <= c->h_pin_bytes) return SLAMFE_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_pin) HIPCHK(c, hipHostFree(c->h_pin));
+    c->h_pin = nullptr;
+    c->h_pin_bytes = 0;
+    size_t want = bytes + bytes / 2 + 4096;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_pin, want, 0));
+    c->h_pin_bytes = want;
+    return SLAMFE_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Per-axis taps of the fixed-point bilinear resize: source offset and the 8.8
 // weight of the right/lower tap, packed as ofs | c1 << 16.  The sample
@@ -287,25 +309,64 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     return SLAMFE_OK;
 }
 
+int ensure_host_staging(slamfe_ctx* c)
+{
+    if (c->h_in) return SLAMFE_OK;
+    const size_t B = (size_t)c->p.max_batch;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_in, B * (size_t)c->p.max_width * c->p.max_height * 3, 0));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_out, B * (size_t)c->max_kp * (sizeof(slamfe_keypoint) + 32), 0));
+    return SLAMFE_OK;
+}
+
+// Copy the results of `nf` resident frames (slots[i]) to the caller: one
+// transfer + wait for the counts, one for the rows, through pinned memory.
+int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kps, uint8_t* desc,
+                    int cap, int* n_out)
+{
+    int rc = ensure_host_staging(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    for (int i = 0; i < nf; ++i)
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt + i, c->kp_count + slots[i], sizeof(int32_t),
+                                 hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int worst = SLAMFE_OK;
+    const size_t K = (size_t)c->max_kp;
+    slamfe_keypoint* hk = reinterpret_cast<slamfe_keypoint*>(c->h_out);
+    uint8_t* hd = c->h_out + (size_t)c->p.max_batch * K * sizeof(slamfe_keypoint);
+    std::vector<int> ncopy((size_t)nf, 0);
+    for (int i = 0; i < nf; ++i) {
+        int n = c->h_cnt[i];
+        if (n_out) n_out[i] = n;
+        if (n > c->max_kp) {
+            worst = fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the context's max_keypoints %d", n,
+                         c->max_kp);
+            continue;
+        }
+        if ((kps || desc) && n > cap) {
+            worst = fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the caller's capacity %d", n, cap);
+            continue;
+        }
+        ncopy[(size_t)i] = n;
+        if (n > 0 && kps)
+            HIPCHK(c, hipMemcpyAsync(hk + (size_t)i * K, c->kps + (size_t)slots[i] * K,
+                                     (size_t)n * sizeof(slamfe_keypoint), hipMemcpyDeviceToHost, s));
+        if (n > 0 && desc)
+            HIPCHK(c, hipMemcpyAsync(hd + (size_t)i * K * 32, c->desc + (size_t)slots[i] * K * 32,
+                                     (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int i = 0; i < nf; ++i) {
+        size_t n = (size_t)ncopy[(size_t)i];
+        if (n && kps) memcpy(kps + (size_t)i * cap, hk + (size_t)i * K, n * sizeof(slamfe_keypoint));
+        if (n && desc) memcpy(desc + (size_t)i * cap * 32, hd + (size_t)i * K * 32, n * 32);
+    }
+    return worst;
+}
+
 int download_frame(slamfe_ctx* c, int slot, slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out)
 {
-    int32_t n = 0;
-    HIPCHK(c, hipMemcpyAsync(&n, c->kp_count + slot, sizeof n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (n_out) *n_out = n;
-    if (n > c->max_kp)
-        return fail(c, SLAMFE_E_CAPACITY,
-                    "%d keypoints exceed the context's max_keypoints %d", n, c->max_kp);
-    if ((kps || desc) && n > cap)
-        return fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the caller's capacity %d", n, cap);
-    if (n > 0 && kps)
-        HIPCHK(c, hipMemcpyAsync(kps, c->kps + (size_t)slot * c->max_kp, (size_t)n * sizeof *kps,
-                                 hipMemcpyDeviceToHost, c->stream));
-    if (n > 0 && desc)
-        HIPCHK(c, hipMemcpyAsync(desc, c->desc + (size_t)slot * c->max_kp * 32, (size_t)n * 32,
-                                 hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SLAMFE_OK;
+    return download_frames(c, &slot, 1, kps, desc, cap, n_out);
 }
 
 } // namespace
@@ -350,6 +411,10 @@ void slamfe_destroy(slamfe_ctx* c)
                     c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -426,6 +491,7 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     HIPCHK(c, hipMalloc(&c->kps, S * K * sizeof(slamfe_keypoint)));
     HIPCHK(c, hipMalloc(&c->desc, S * K * 32));
     HIPCHK(c, hipMemset(c->kp_count, 0, S * sizeof(int32_t)));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, (B > 16 ? B : 16) * sizeof(int32_t), 0));
     HIPCHK(c, hipMalloc(&c->match_out, K * sizeof(slamfe_match2)));
     slamfe_match_plan(c->max_kp, c->max_kp, 1, &c->fm_qpt, &c->fm_chunk, &c->fm_nchunks);
     int rc = grow(c, c->match_part, (size_t)c->fm_nchunks * K * 8);
@@ -468,25 +534,27 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
         return fail(c, SLAMFE_E_INVALID, "bad frame description %dx%d stride %d channels %d", w, h,
                     stride, channels);
     const size_t row = (size_t)w * channels, fbytes = row * h;
+    int rc = ensure_host_staging(c);
+    if (rc) return rc;
+    // the staging buffers may still feed the previous call's queued copies
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) {
         if (!imgs[i]) return fail(c, SLAMFE_E_INVALID, "imgs[%d] is NULL", i);
-        HIPCHK(c, hipMemcpy2DAsync(c->in_stage + (size_t)i * fbytes, row, imgs[i], (size_t)stride, row,
-                                   (size_t)h, hipMemcpyHostToDevice, c->stream));
+        uint8_t* dst = c->h_in + (size_t)i * fbytes;
+        if ((size_t)stride == row) memcpy(dst, imgs[i], fbytes);
+        else
+            for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * row, imgs[i] + (size_t)y * stride, row);
     }
+    HIPCHK(c, hipMemcpyAsync(c->in_stage, c->h_in, (size_t)n * fbytes, hipMemcpyHostToDevice, c->stream));
     std::vector<uint64_t> hd((size_t)n);
-    int rc = run_extract(c, c->in_stage, n, w, h, (int)row, fbytes, channels, hd.data());
+    rc = run_extract(c, c->in_stage, n, w, h, (int)row, fbytes, channels, hd.data());
     if (rc) return rc;
-    int worst = SLAMFE_OK;
+    std::vector<int> slots((size_t)n);
     for (int i = 0; i < n; ++i) {
         if (frame_handles) frame_handles[i] = hd[(size_t)i];
-        int cnt = 0;
-        rc = download_frame(c, slot_of(c, hd[(size_t)i]), kps ? kps + (size_t)i * cap : nullptr,
-                            desc ? desc + (size_t)i * cap * 32 : nullptr, cap, &cnt);
-        if (n_out) n_out[i] = cnt;
-        if (rc == SLAMFE_E_DEVICE) return rc;
-        if (rc) worst = rc;
+        slots[(size_t)i] = slot_of(c, hd[(size_t)i]);
     }
-    return worst;
+    return download_frames(c, slots.data(), n, kps, desc, cap, n_out);
 }
 
 int slamfe_extract(slamfe_ctx* c, const uint8_t* img, int w, int h, int stride, int channels,
@@ -538,17 +606,24 @@ int slamfe_match_knn2(slamfe_ctx* c, const uint8_t* query, int nq, const uint8_t
     int qpt, chunk, nchunks;
     slamfe_match_plan(nq, nt, 1, &qpt, &chunk, &nchunks);
     if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->match_q.p, query, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-    if (nt > 0)
-        HIPCHK(c, hipMemcpyAsync(c->match_t.p, train, (size_t)nt * 32, hipMemcpyHostToDevice,
+    const size_t oq = 0, ot = align256((size_t)nq * 32), oo = ot + align256((size_t)nt * 32);
+    if ((rc = pin_reserve(c, oo + (size_t)nq * sizeof(slamfe_match2)))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // the bounce buffer may still be in use
+    memcpy(c->h_pin + oq, query, (size_t)nq * 32);
+    HIPCHK(c, hipMemcpyAsync(c->match_q.p, c->h_pin + oq, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (nt > 0) {
+        memcpy(c->h_pin + ot, train, (size_t)nt * 32);
+        HIPCHK(c, hipMemcpyAsync(c->match_t.p, c->h_pin + ot, (size_t)nt * 32, hipMemcpyHostToDevice,
                                  c->stream));
+    }
     KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)c->match_q.p, nq, nullptr,
                                 (const uint8_t*)c->match_t.p, nt, nullptr, nq, qpt, chunk, nchunks,
                                 (uint32_t*)c->match_part.p, c->p.ratio, (slamfe_match2*)c->match_o.p,
                                 nullptr, 0, 1, 0, 0, 0));
-    HIPCHK(c, hipMemcpyAsync(out, c->match_o.p, (size_t)nq * sizeof(slamfe_match2),
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + oo, c->match_o.p, (size_t)nq * sizeof(slamfe_match2),
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_pin + oo, (size_t)nq * sizeof(slamfe_match2));
     return SLAMFE_OK;
 }
 
@@ -592,18 +667,21 @@ int slamfe_match_frames(slamfe_ctx* c, uint64_t query_frame, uint64_t train_fram
     int rc = slamfe_match_resident(c, query_frame, train_frame, c->match_out);
     if (rc) return rc;
     int sq = slot_of(c, query_frame);
-    int32_t nq = 0;
-    HIPCHK(c, hipMemcpyAsync(&nq, c->kp_count + sq, sizeof nq, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->kp_count + sq, sizeof(int32_t), hipMemcpyDeviceToHost,
+                             c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t nq = c->h_cnt[0];
     if (nq > c->max_kp) nq = c->max_kp;
     if (nq_out) *nq_out = nq;
     if (out) {
         if (nq > cap)
             return fail(c, SLAMFE_E_CAPACITY, "%d match rows exceed the caller's capacity %d", nq, cap);
         if (nq > 0) {
-            HIPCHK(c, hipMemcpyAsync(out, c->match_out, (size_t)nq * sizeof *out,
+            if ((rc = pin_reserve(c, (size_t)nq * sizeof *out))) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->h_pin, c->match_out, (size_t)nq * sizeof *out,
                                      hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            memcpy(out, c->h_pin, (size_t)nq * sizeof *out);
         }
     }
     return SLAMFE_OK;
@@ -644,13 +722,18 @@ int slamfe_map_put(slamfe_ctx* c, const int32_t* point_ids, const uint8_t* desc3
         if (point_ids[i] < 0 || point_ids[i] >= c->p.map_capacity)
             return fail(c, SLAMFE_E_CAPACITY, "point id %d outside map_capacity %d", point_ids[i],
                         c->p.map_capacity);
+    if (n == 0) return SLAMFE_OK;
+    int rc = pin_reserve(c, (size_t)n * 32);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin, desc32, (size_t)n * 32);
     // ids are dense and usually consecutive (Init.cc:296 uses m.getPointsSize()):
     // copy runs of consecutive ids in one transfer each
     int i = 0;
     while (i < n) {
         int j = i + 1;
         while (j < n && point_ids[j] == point_ids[j - 1] + 1) ++j;
-        HIPCHK(c, hipMemcpyAsync(c->map_desc + (size_t)point_ids[i] * 32, desc32 + (size_t)i * 32,
+        HIPCHK(c, hipMemcpyAsync(c->map_desc + (size_t)point_ids[i] * 32, c->h_pin + (size_t)i * 32,
                                  (size_t)(j - i) * 32, hipMemcpyHostToDevice, c->stream));
         i = j;
     }
@@ -679,9 +762,10 @@ int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp
         if (point_ids[j] < 0 || point_ids[j] >= c->p.map_capacity)
             return fail(c, SLAMFE_E_INVALID, "point id %d outside map_capacity %d", point_ids[j],
                         c->p.map_capacity);
-    int32_t nkp = 0;
-    HIPCHK(c, hipMemcpyAsync(&nkp, c->kp_count + slot, sizeof nkp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->kp_count + slot, sizeof(int32_t), hipMemcpyDeviceToHost,
+                             c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t nkp = c->h_cnt[0];
     if (nkp > c->max_kp) nkp = c->max_kp;
     for (int i = 0; i < n_inl; ++i)
         if (kp_idx[i] < 0 || kp_idx[i] >= nkp)
@@ -695,18 +779,25 @@ int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp
     if ((rc = grow(c, c->pj_candn, (size_t)n_inl * 4))) return rc;
     if ((rc = grow(c, c->pj_matched, (size_t)n_inl * 4))) return rc;
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->pj_idx.p, kp_idx, (size_t)n_inl * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->pj_uv.p, uv, (size_t)R * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->pj_ids.p, point_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    const size_t o_idx = 0, o_uv = align256((size_t)n_inl * 4), o_ids = o_uv + align256((size_t)R * 8),
+                 o_out = o_ids + align256((size_t)R * 4);
+    if ((rc = pin_reserve(c, o_out + (size_t)n_inl * 4))) return rc;
+    memcpy(c->h_pin + o_idx, kp_idx, (size_t)n_inl * 4);
+    memcpy(c->h_pin + o_uv, uv, (size_t)R * 8);
+    memcpy(c->h_pin + o_ids, point_ids, (size_t)R * 4);
+    HIPCHK(c, hipMemcpyAsync(c->pj_idx.p, c->h_pin + o_idx, (size_t)n_inl * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->pj_uv.p, c->h_pin + o_uv, (size_t)R * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->pj_ids.p, c->h_pin + o_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
     KCHK(c, slamfe_launch_projection(s, c->kps + (size_t)slot * c->max_kp,
                                      c->desc + (size_t)slot * c->max_kp * 32, nkp,
                                      (const int32_t*)c->pj_idx.p, n_inl, (const float*)c->pj_uv.p,
                                      (const int32_t*)c->pj_ids.p, R, c->map_desc, radius, max_hamming,
                                      (uint32_t*)c->pj_cand.p, (int32_t*)c->pj_candn.p,
                                      (int32_t*)c->pj_matched.p));
-    HIPCHK(c, hipMemcpyAsync(matched_point_id, c->pj_matched.p, (size_t)n_inl * 4,
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + o_out, c->pj_matched.p, (size_t)n_inl * 4,
                              hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    memcpy(matched_point_id, c->h_pin + o_out, (size_t)n_inl * 4);
     return SLAMFE_OK;
 }
 
