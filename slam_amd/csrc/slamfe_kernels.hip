@@ -1166,62 +1166,128 @@ __global__ __launch_bounds__(256) void k_proj_candidates(
     if (tid == 0) cand_n[i] = (int32_t)(n < PROJ_K ? n : (PROJ_K | (n > PROJ_K ? (1 << 30) : 0)));
 }
 
-__global__ __launch_bounds__(64) void k_proj_resolve(
+#define PROJ_CHUNK 64 /* inliers per staged chunk */
+
+__global__ __launch_bounds__(256) void k_proj_resolve(
     const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
     const int32_t* __restrict__ kp_idx, int n_inl, const float2* __restrict__ uv,
     const int32_t* __restrict__ point_ids, int R, const uint32_t* __restrict__ map_desc,
     float radius, int max_hamming, const uint32_t* __restrict__ cand,
     const int32_t* __restrict__ cand_n, int32_t* __restrict__ matched)
 {
-    extern __shared__ uint32_t taken[]; // one bit per visible point, (R+31)/32 words
-    const int lane = threadIdx.x;
-    for (int w = lane; w < (R + 31) / 32; w += 64) taken[w] = 0;
+    // One workgroup of four waves.  Wave 0 walks the inliers in order (the
+    // serial part); waves 1-3 meanwhile copy the next chunk of 64 candidate
+    // lists from global memory into the other LDS buffer, so the chain never
+    // waits on HBM.  LDS: two buffers of 64*PROJ_K keys + 64 list headers,
+    // 64 answers, then one bit per visible point ((R+31)/32 words).
+    extern __shared__ uint32_t plds[];
+    const int BUF = PROJ_CHUNK * PROJ_K + PROJ_CHUNK;
+    int32_t* res = reinterpret_cast<int32_t*>(plds + 2 * BUF);
+    uint32_t* taken = plds + 2 * BUF + PROJ_CHUNK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int w = tid; w < (R + 31) / 32; w += 256) taken[w] = 0;
+
+    auto load_chunk = [&](int c0, int buf, int t0, int nt) {
+        // threads t0 .. t0+nt-1 of the workgroup copy chunk c0 into buffer buf
+        const int nc = min(PROJ_CHUNK, n_inl - c0);
+        if (nc <= 0) return;
+        uint32_t* st = plds + buf * BUF;
+        int32_t* sn = reinterpret_cast<int32_t*>(st + PROJ_CHUNK * PROJ_K);
+        const int t = tid - t0;
+        if (t < PROJ_CHUNK) sn[t] = t < nc ? cand_n[c0 + t] : 0;
+        const uint32_t* src = cand + (size_t)c0 * PROJ_K;
+#pragma unroll 4
+        for (int e = t; e < nc * PROJ_K; e += nt) st[e] = src[e];
+    };
+
+    load_chunk(0, 0, 0, 256);
     __syncthreads();
-    for (int i = 0; i < n_inl; ++i) {
-        const int cn = cand_n[i];
-        int result = -1; // position j of the chosen point
-        bool rescan = cn < 0;
-        if (!rescan) {
-            const int n = cn & 0xffff;
-            // first stored candidate whose point is still available
-            uint32_t key = 0xffffffffu;
-            bool avail = false;
-            if (lane < n) {
-                key = cand[(size_t)i * PROJ_K + lane];
-                uint32_t j = key & 0xfffffu;
-                avail = !((taken[j >> 5] >> (j & 31)) & 1u);
-            }
-            unsigned long long m = __ballot(avail);
-            if (m) {
-                int first = __ffsll((long long)m) - 1;
-                result = (int)(__shfl(key, first) & 0xfffffu);
-            } else if (cn & (1 << 30)) {
-                rescan = true;
-            }
-        }
-        if (rescan) {
-            const int idx = kp_idx[i];
-            uint32_t best = 0xffffffffu;
-            if (idx >= 0 && idx < nkp) {
-                const float kx = kps[idx].x, ky = kps[idx].y;
-                const uint32_t* qd = fdesc + (size_t)idx * 8;
-                for (int j = lane; j < R; j += 64) {
-                    if ((taken[j >> 5] >> (j & 31)) & 1u) continue;
-                    float2 p = uv[j];
-                    if (!proj_gate(p.x, p.y, kx, ky, radius)) continue;
-                    int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
-                    if (h <= max_hamming) best = min(best, ((uint32_t)h << 20) | (uint32_t)j);
+    int buf = 0;
+    for (int c0 = 0; c0 < n_inl; c0 += PROJ_CHUNK, buf ^= 1) {
+        const int nc = min(PROJ_CHUNK, n_inl - c0);
+        if (wave != 0) {
+            load_chunk(c0 + PROJ_CHUNK, buf ^ 1, 64, 192);
+        } else {
+            const uint32_t* stage = plds + buf * BUF;
+            const int32_t* stage_n = reinterpret_cast<const int32_t*>(stage + PROJ_CHUNK * PROJ_K);
+            // Software-pipelined serial chain.  List headers live in a register
+            // (lane ii holds inlier ii's header, fetched with readlane); keys
+            // are read from LDS two iterations ahead and the consumed-bit of
+            // each key's point one iteration ahead, i.e. before the current
+            // inlier's choice is recorded -- that one missing update is patched
+            // by comparing against `last`.  The chain itself is ballot ->
+            // find-first -> readlane: registers only.
+            volatile uint32_t* vt = taken;
+            const int cn_reg = stage_n[lane];
+            auto load_key = [&](int ii) -> uint32_t {
+                if (ii >= nc) return 0xffffffffu;
+                int c = __builtin_amdgcn_readlane(cn_reg, ii);
+                int n = c < 0 ? 0 : (c & 0xffff);
+                return lane < n ? stage[ii * PROJ_K + lane] : 0xffffffffu;
+            };
+            auto load_tk = [&](uint32_t k) -> bool {
+                if (k == 0xffffffffu) return false;
+                uint32_t j = k & 0xfffffu;
+                return (vt[j >> 5] >> (j & 31)) & 1u;
+            };
+            uint32_t key0 = load_key(0), key1 = load_key(1);
+            bool tk0 = load_tk(key0);
+            int last = -1;
+            for (int ii = 0; ii < nc; ++ii) {
+                const int i = c0 + ii;
+                const int cn = __builtin_amdgcn_readlane(cn_reg, ii);
+                const uint32_t key = key0;
+                const bool tk = tk0;
+                const uint32_t key2 = load_key(ii + 2);
+                const bool tk1 = load_tk(key1); // reads `taken` before this inlier's update
+                int result = -1; // position j of the chosen point
+                bool rescan = cn < 0;
+                if (!rescan) {
+                    const int j = (int)(key & 0xfffffu);
+                    const bool avail = key != 0xffffffffu && !tk && j != last;
+                    unsigned long long m = __ballot(avail);
+                    if (m) {
+                        int first = __ffsll((long long)m) - 1;
+                        result = (int)((uint32_t)__builtin_amdgcn_readlane((int)key, first) & 0xfffffu);
+                    } else if (cn & (1 << 30)) {
+                        rescan = true;
+                    }
                 }
-            }
+                if (rescan) { // the list overflowed and ran dry (or was never ranked)
+                    const int idx = kp_idx[i];
+                    uint32_t best = 0xffffffffu;
+                    if (idx >= 0 && idx < nkp) {
+                        const float kx = kps[idx].x, ky = kps[idx].y;
+                        const uint32_t* qd = fdesc + (size_t)idx * 8;
+                        for (int j = lane; j < R; j += 64) {
+                            if ((vt[j >> 5] >> (j & 31)) & 1u) continue;
+                            float2 p = uv[j];
+                            if (!proj_gate(p.x, p.y, kx, ky, radius)) continue;
+                            int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
+                            if (h <= max_hamming) best = min(best, ((uint32_t)h << 20) | (uint32_t)j);
+                        }
+                    }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
-            if (best != 0xffffffffu) result = (int)(best & 0xfffffu);
+                    for (int o = 32; o > 0; o >>= 1)
+                        best = min(best, (uint32_t)__shfl_xor((int)best, o));
+                    if (best != 0xffffffffu) result = (int)(best & 0xfffffu);
+                }
+                if (lane == 0) {
+                    res[ii] = result;
+                    if (result >= 0) atomicOr(&taken[result >> 5], 1u << (result & 31));
+                }
+                last = result;
+                key0 = key1;
+                tk0 = tk1;
+                key1 = key2;
+            }
         }
-        if (lane == 0) {
-            matched[i] = result >= 0 ? point_ids[result] : -1;
-            if (result >= 0) taken[result >> 5] |= 1u << (result & 31);
+        __syncthreads();
+        if (tid < nc) {
+            int r = res[tid];
+            matched[c0 + tid] = r >= 0 ? point_ids[r] : -1;
         }
-        __syncthreads(); // one wave: orders lane 0's LDS update before the next reads
+        __syncthreads();
     }
 }
 
@@ -1405,7 +1471,10 @@ int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const ui
                        reinterpret_cast<const float2*>(uv), point_ids, R,
                        reinterpret_cast<const uint32_t*>(map_desc), radius, max_hamming, cand, cand_n);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), ((size_t)R + 31) / 32 * 4 + 4, s, kps,
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(256),
+                       (2 * (PROJ_CHUNK * PROJ_K + PROJ_CHUNK) + PROJ_CHUNK) * 4 +
+                           ((size_t)R + 31) / 32 * 4 + 4,
+                       s, kps,
                        reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
                        reinterpret_cast<const float2*>(uv), point_ids, R,
                        reinterpret_cast<const uint32_t*>(map_desc), radius, max_hamming, cand, cand_n,
@@ -1424,7 +1493,7 @@ int slamfe_kernels_init(size_t sort_lds_bytes)
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SLAMFE_PROJ_MAX_POINTS / 8 + 64);
+                            SLAMFE_PROJ_MAX_POINTS / 8 + (2 * (PROJ_CHUNK * PROJ_K + PROJ_CHUNK) + PROJ_CHUNK) * 4 + 64);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
