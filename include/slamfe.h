@@ -129,6 +129,19 @@ int slamfe_extract_batch(slamfe_ctx* ctx, const uint8_t* const* imgs, int n, int
                          int stride, int channels, slamfe_keypoint* kps, uint8_t* desc, int cap,
                          int* n_out, uint64_t* frame_handles);
 
+/* Replaces cv::resize(frame, frame, cv::Size(), fx, fy) (Init.cc:103 and
+ * Init.cc:126; the reference uses 0.99) followed by Init::extractKeyPoints on
+ * the resized frame (Init.cc:113, Init.cc:130).  bgr: the decoded 8-bit BGR
+ * frame.  The resize is OpenCV's INTER_LINEAR (11-bit fixed point), output size
+ * (cvRound(w*fx), cvRound(h*fy)) returned in *out_w, *out_h.  resized_bgr, if not
+ * NULL, receives the resized BGR frame (out_h rows of out_w*3 bytes), which the
+ * reference still needs on the host (Init.cc:294, Init.cc:320-321).  Factors
+ * must lie in (0.5, 1].  Everything else as slamfe_extract. */
+int slamfe_extract_scaled_bgr(slamfe_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, double fx,
+                              double fy, uint8_t* resized_bgr, int* out_w, int* out_h,
+                              slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                              uint64_t* frame_handle);
+
 /* Init.cc:75-78 for frames that already sit in device memory (frame i at
  * d_imgs + i*frame_stride_bytes).  Asynchronous on the context's stream; no
  * host synchronisation.  Results stay device-resident under the handles. */

@@ -38,6 +38,78 @@ void orc_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray, i
     }
 }
 
+/* ------------------------------------------------------- frame resize */
+
+void orc_scaled_size(int sw, int sh, double fx, double fy, int* dw, int* dh)
+{
+    *dw = slamfe_round_d((double)sw * fx);
+    *dh = slamfe_round_d((double)sh * fy);
+}
+
+static short sat_short(float v)
+{
+    int r = slamfe_round_f(v);
+    return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
+/* Init.cc:103,126.  Per axis: position f = (float)((d + 0.5) * (1/fx) - 0.5),
+ * s = floor(f), weights saturate_cast<short>((1-f')*2048), (f'*2048) in float;
+ * horizontal pass in int, vertical pass
+ *   ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2. */
+void orc_resize_linear_8u(const uint8_t* src, int sw, int sh, int sstride, int cn, double fx,
+                          double fy, uint8_t* dst, int dstride)
+{
+    int dw, dh;
+    orc_scaled_size(sw, sh, fx, fy, &dw, &dh);
+    double scale_x = 1. / fx, scale_y = 1. / fy;
+    int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+    short* ia = (short*)malloc(sizeof(short) * 2 * (size_t)dw);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; ++dx) {
+        float f = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(f);
+        f -= (float)sx;
+        if (sx < 0) { f = 0; sx = 0; }
+        if (sx + 1 >= sw) {
+            if (dx < xmax) xmax = dx;
+            if (sx >= sw - 1) { f = 0; sx = sw - 1; }
+        }
+        xofs[dx] = sx;
+        ia[2 * dx] = sat_short((1.f - f) * 2048.f);
+        ia[2 * dx + 1] = sat_short(f * 2048.f);
+    }
+    int* rows[2];
+    rows[0] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+    rows[1] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+    for (int dy = 0; dy < dh; ++dy) {
+        float f = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(f);
+        f -= (float)sy;
+        short b0 = sat_short((1.f - f) * 2048.f), b1 = sat_short(f * 2048.f);
+        for (int k = 0; k < 2; ++k) {
+            int y = sy + k;
+            y = y >= 0 ? (y < sh ? y : sh - 1) : 0;
+            const uint8_t* S = src + (size_t)y * sstride;
+            int* D = rows[k];
+            for (int dx = 0; dx < dw; ++dx)
+                for (int c = 0; c < cn; ++c) {
+                    int sx = xofs[dx] * cn + c;
+                    D[dx * cn + c] = dx < xmax ? S[sx] * ia[2 * dx] + S[sx + cn] * ia[2 * dx + 1]
+                                               : S[sx] * 2048;
+                }
+        }
+        uint8_t* d = dst + (size_t)dy * dstride;
+        for (int x = 0; x < dw * cn; ++x) {
+            int v = (((b0 * (rows[0][x] >> 4)) >> 16) + ((b1 * (rows[1][x] >> 4)) >> 16) + 2) >> 2;
+            d[x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    free(xofs);
+    free(ia);
+    free(rows[0]);
+    free(rows[1]);
+}
+
 /* ------------------------------------------------------------------ FAST */
 
 /* Score of a pixel that passed the segment test: with d[k] = v - ring[k],

@@ -36,6 +36,15 @@ typedef struct orc_corner {
 /* cv::cvtColor(frame, frame, COLOR_BGR2GRAY), Init.cc:75. */
 void orc_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray, int gstride);
 
+/* cv::resize(frame, frame, cv::Size(), fx, fy) of Init.cc:103 / Init.cc:126 for
+ * 8-bit images with cn interleaved channels: INTER_LINEAR with 11-bit fixed
+ * point coefficients (OpenCV's own code path; a build that routes resize
+ * through a vendor primitive library may round differently).  The output size
+ * is (cvRound(sw*fx), cvRound(sh*fy)); dst rows hold dw*cn bytes. */
+void orc_resize_linear_8u(const uint8_t* src, int sw, int sh, int sstride, int cn, double fx,
+                          double fy, uint8_t* dst, int dstride);
+void orc_scaled_size(int sw, int sh, double fx, double fy, int* dw, int* dh);
+
 /* FAST-9/16 score of every pixel (0 where the segment test fails), the map
  * cv::FastFeatureDetector builds row by row before non-max suppression
  * (Init.cc:64, Init.cc:76). */

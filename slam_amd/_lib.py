@@ -26,6 +26,8 @@ SIGNATURES = {
     "slamfe_last_error": (C.c_char_p, [ctxp]),
     "slamfe_extract": (C.c_int, [ctxp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int,
                                  i32p, u64p]),
+    "slamfe_extract_scaled_bgr": (C.c_int, [ctxp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                            vp, i32p, i32p, vp, vp, C.c_int, i32p, u64p]),
     "slamfe_extract_batch": (C.c_int, [ctxp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, vp, C.c_int, i32p, u64p]),
     "slamfe_extract_resident": (C.c_int, [ctxp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,

@@ -78,6 +78,7 @@ struct slamfe_ctx {
     Scratch match_part, match_q, match_t, match_o;
     uint8_t* map_desc = nullptr;
     Scratch pj_idx, pj_uv, pj_ids, pj_cand, pj_candn, pj_matched;
+    Scratch ing_taps, ing_bgr;
 };
 
 namespace {
@@ -271,6 +272,7 @@ int slot_of(const slamfe_ctx* c, uint64_t handle)
 }
 
 // Queue the whole extraction of n device-resident frames.
+// d_imgs == nullptr: level 0 of the pyramid has already been written (scaled ingest).
 int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int stride,
                 size_t frame_stride, int channels, uint64_t* handles)
 {
@@ -293,8 +295,9 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     }
     c->next_seq += (uint64_t)n;
 
-    KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
-                                 g.frame_bytes, g.lv[0].pitch));
+    if (d_imgs)
+        KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
+                                     g.frame_bytes, g.lv[0].pitch));
     KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
     KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
                                     c->p.edge_threshold, c->cand, c->cand_cnt));
@@ -408,7 +411,8 @@ void slamfe_destroy(slamfe_ctx* c)
                     c->band_off, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
                     c->kp_count, c->kps, c->desc, c->kp_mom, c->kp_rot, c->match_out, c->map_desc, c->match_part.p,
                     c->match_q.p, c->match_t.p, c->match_o.p, c->pj_idx.p, c->pj_uv.p,
-                    c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p};
+                    c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p, c->ing_taps.p,
+                    c->ing_bgr.p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -563,6 +567,89 @@ int slamfe_extract(slamfe_ctx* c, const uint8_t* img, int w, int h, int stride, 
     const uint8_t* one[1] = {img};
     return slamfe_extract_batch(c, one, 1, w, h, stride, channels, kps, desc, cap, n_out,
                                 frame_handle);
+}
+
+namespace {
+short sat_short(float v)
+{
+    int r = slamfe_round_f(v);
+    return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+} // namespace
+
+int slamfe_extract_scaled_bgr(slamfe_ctx* c, const uint8_t* bgr, int w, int h, int stride, double fx,
+                              double fy, uint8_t* resized_bgr, int* out_w, int* out_h,
+                              slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                              uint64_t* frame_handle)
+{
+    if (!c || !bgr) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    if (w < 2 || h < 2 || stride < w * 3 || !(fx > 0.5 && fx <= 1.0) || !(fy > 0.5 && fy <= 1.0))
+        return fail(c, SLAMFE_E_INVALID, "scaled ingest takes a BGR frame and factors in (0.5, 1]");
+    if (w > c->p.max_width || h > c->p.max_height)
+        return fail(c, SLAMFE_E_INVALID, "frame %dx%d outside the context's maximum %dx%d", w, h,
+                    c->p.max_width, c->p.max_height);
+    const int dw = slamfe_round_d((double)w * fx), dh = slamfe_round_d((double)h * fy);
+    if (out_w) *out_w = dw;
+    if (out_h) *out_h = dh;
+    int rc = ensure_geometry(c, dw, dh);
+    if (rc) return rc;
+    if ((rc = ensure_host_staging(c))) return rc;
+    // taps exactly as cv::resize computes them (float positions, 11-bit weights)
+    std::vector<uint32_t> taps(2 * (size_t)(dw + dh));
+    const double scale_x = 1. / fx, scale_y = 1. / fy;
+    int xmax = dw;
+    for (int dx = 0; dx < dw; ++dx) {
+        float f = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(f);
+        f -= (float)sx;
+        if (sx < 0) { f = 0; sx = 0; }
+        if (sx + 1 >= w) {
+            if (dx < xmax) xmax = dx;
+            if (sx >= w - 1) { f = 0; sx = w - 1; }
+        }
+        uint32_t a0 = (uint16_t)sat_short((1.f - f) * 2048.f), a1 = (uint16_t)sat_short(f * 2048.f);
+        taps[2 * (size_t)dx] = (uint32_t)sx | (dx >= xmax ? 0x80000000u : 0u);
+        taps[2 * (size_t)dx + 1] = a0 | (a1 << 16);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float f = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(f);
+        f -= (float)sy;
+        int y0 = sy < 0 ? 0 : (sy < h ? sy : h - 1), y1 = sy + 1 < 0 ? 0 : (sy + 1 < h ? sy + 1 : h - 1);
+        uint32_t b0 = (uint16_t)sat_short((1.f - f) * 2048.f), b1 = (uint16_t)sat_short(f * 2048.f);
+        taps[2 * (size_t)(dw + dy)] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+        taps[2 * (size_t)(dw + dy) + 1] = b0 | (b1 << 16);
+    }
+    const size_t tap_bytes = taps.size() * sizeof(uint32_t);
+    const int bpitch = (dw * 3 + 15) / 16 * 16;
+    if ((rc = grow(c, c->ing_taps, tap_bytes))) return rc;
+    if (resized_bgr && (rc = grow(c, c->ing_bgr, (size_t)bpitch * dh))) return rc;
+    const size_t row = (size_t)w * 3, fbytes = row * h;
+    if ((rc = pin_reserve(c, tap_bytes + (resized_bgr ? (size_t)bpitch * dh : 0)))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int y = 0; y < h; ++y) memcpy(c->h_in + (size_t)y * row, bgr + (size_t)y * stride, row);
+    memcpy(c->h_pin, taps.data(), tap_bytes);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->in_stage, c->h_in, fbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->ing_taps.p, c->h_pin, tap_bytes, hipMemcpyHostToDevice, s));
+    const uint32_t* dt = (const uint32_t*)c->ing_taps.p;
+    KCHK(c, slamfe_launch_ingest_scaled(s, c->in_stage, (int)row, dt, dt + 2 * (size_t)dw, dw, dh, c->pyr,
+                                        c->geom.lv[0].pitch, resized_bgr ? (uint8_t*)c->ing_bgr.p : nullptr,
+                                        bpitch));
+    uint64_t hd = 0;
+    rc = run_extract(c, nullptr, 1, dw, dh, dw, 0, 1, &hd);
+    if (rc) return rc;
+    if (frame_handle) *frame_handle = hd;
+    if (resized_bgr)
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + tap_bytes, c->ing_bgr.p, (size_t)bpitch * dh,
+                                 hipMemcpyDeviceToHost, s));
+    int slot = slot_of(c, hd);
+    rc = download_frames(c, &slot, 1, kps, desc, cap, n_out);
+    if (resized_bgr)
+        for (int y = 0; y < dh; ++y)
+            memcpy(resized_bgr + (size_t)y * dw * 3, c->h_pin + tap_bytes + (size_t)y * bpitch, (size_t)dw * 3);
+    return rc;
 }
 
 int slamfe_frame_download(slamfe_ctx* c, uint64_t frame_handle, slamfe_keypoint* kps, uint8_t* desc,

@@ -12,6 +12,9 @@
 int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int stride,
                          size_t frame_stride, int channels, int nframes, uint8_t* pyr,
                          uint32_t frame_bytes, int pitch);
+int slamfe_launch_ingest_scaled(hipStream_t s, const uint8_t* d_in, int stride, const uint32_t* xt,
+                                const uint32_t* yt, int dw, int dh, uint8_t* gray, int gpitch,
+                                uint8_t* bgr_out, int bpitch);
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
                           const uint32_t* taps);
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,

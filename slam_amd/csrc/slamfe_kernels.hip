@@ -101,6 +101,62 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ in, 
 }
 
 // ---------------------------------------------------------------------------
+// K0  scaled ingest: cv::resize(frame, frame, Size(), fx, fy) on the BGR frame
+//     (Init.cc:103, Init.cc:126; INTER_LINEAR, 11-bit fixed point) fused with
+//     the BGR -> gray conversion of Init.cc:75.  A lane produces 4 pixels: the
+//     resized BGR values (optionally stored, the host still needs that frame
+//     for Init.cc:294) and their gray values as one dword of pyramid level 0.
+//     xt[dx] = {sx | single << 31, a0 | a1 << 16}, yt[dy] = {y0 | y1 << 16, b0 | b1 << 16}.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest_scaled(const uint8_t* __restrict__ in, int stride,
+                                                       const uint2* __restrict__ xt,
+                                                       const uint2* __restrict__ yt, int dw, int dh,
+                                                       uint8_t* __restrict__ gray, int gpitch,
+                                                       uint8_t* __restrict__ bgr_out, int bpitch)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const uint2 ty = yt[y];
+    const uint8_t* S0 = in + (size_t)(ty.x & 0xffffu) * stride;
+    const uint8_t* S1 = in + (size_t)(ty.x >> 16) * stride;
+    const int b0 = (int)(ty.y & 0xffffu), b1 = (int)(ty.y >> 16);
+    uint32_t g4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (x + k >= dw) break;
+        const uint2 tx = xt[x + k];
+        const int sx = (int)(tx.x & 0x7fffffffu) * 3;
+        const bool single = tx.x >> 31;
+        const int a0 = (int)(tx.y & 0xffffu), a1 = (int)(tx.y >> 16);
+        int v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int r0, r1;
+            if (single) {
+                r0 = S0[sx + c] * 2048;
+                r1 = S1[sx + c] * 2048;
+            } else {
+                r0 = S0[sx + c] * a0 + S0[sx + 3 + c] * a1;
+                r1 = S1[sx + c] * a0 + S1[sx + 3 + c] * a1;
+            }
+            int t = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v[c] = min(max(t, 0), 255);
+        }
+        if (bgr_out) {
+            uint8_t* o = bgr_out + (size_t)y * bpitch + (size_t)(x + k) * 3;
+            o[0] = (uint8_t)v[0];
+            o[1] = (uint8_t)v[1];
+            o[2] = (uint8_t)v[2];
+        }
+        uint32_t gv = (uint32_t)((v[0] * SLAMFE_B2Y + v[1] * SLAMFE_G2Y + v[2] * SLAMFE_R2Y +
+                                  (1 << (SLAMFE_GRAY_SHIFT - 1))) >> SLAMFE_GRAY_SHIFT);
+        g4 |= gv << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(gray + (size_t)y * gpitch + x) = g4;
+}
+
+// ---------------------------------------------------------------------------
 // K2  pyramid: level l from level l-1, INTER_LINEAR_EXACT fixed point
 //     (the cumulative resize chain inside cv::ORB).
 //
@@ -1315,6 +1371,18 @@ int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int s
     int aligned16 = ((uintptr_t)d_in % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;
     hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, d_in, w, h, stride, frame_stride, channels,
                        pyr, frame_bytes, pitch, aligned16);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_ingest_scaled(hipStream_t s, const uint8_t* d_in, int stride, const uint32_t* xt,
+                                const uint32_t* yt, int dw, int dh, uint8_t* gray, int gpitch,
+                                uint8_t* bgr_out, int bpitch)
+{
+    dim3 grid((dw + 255) / 256, (dh + 3) / 4);
+    hipLaunchKernelGGL(k_ingest_scaled, grid, dim3(256), 0, s, d_in, stride,
+                       reinterpret_cast<const uint2*>(xt), reinterpret_cast<const uint2*>(yt), dw, dh,
+                       gray, gpitch, bgr_out, bpitch);
     LAUNCH_CHECK();
     return 0;
 }

@@ -135,6 +135,25 @@ class FrontEnd:
         return [Frame(handles[i], kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy())
                 for i in range(n)]
 
+    def extract_scaled_bgr(self, frame: np.ndarray, fx: float = 0.99, fy: float = 0.99):
+        """``cv::resize(frame, frame, Size(), fx, fy)`` (Init.cc:103,126) followed by
+        ``extractKeyPoints``.  Returns (Frame, resized BGR frame)."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w, ch = frame.shape
+        if ch != 3:
+            raise ValueError("a BGR frame is expected")
+        cap = self.max_keypoints
+        kps = np.zeros(cap, abi.KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        resized = np.zeros(h * w * 3, np.uint8)
+        n, dw, dh = C.c_int32(), C.c_int32(), C.c_int32()
+        hd = C.c_uint64()
+        self._check(self._lib.slamfe_extract_scaled_bgr(
+            self._ctx, frame.ctypes.data, w, h, w * 3, fx, fy, resized.ctypes.data, C.byref(dw),
+            C.byref(dh), kps.ctypes.data, desc.ctypes.data, cap, C.byref(n), C.byref(hd)))
+        out = resized[:dw.value * dh.value * 3].reshape(dh.value, dw.value, 3).copy()
+        return Frame(hd.value, kps[:n.value].copy(), desc[:n.value].copy()), out
+
     def extract_resident(self, d_ptr: int, n: int, w: int, h: int, stride: int,
                          frame_stride: int, channels: int = 1):
         """Asynchronous extraction of frames already in device memory."""

@@ -135,6 +135,32 @@ public:
         return handle;
     }
 
+    // cv::resize(frame, frame, cv::Size(), fx, fy) (Init.cc:103, Init.cc:126) followed
+    // by Init::extractKeyPoints on the resized frame (Init.cc:113, Init.cc:130).
+    // resized receives the resized BGR frame, which the caller keeps using on
+    // the host (Init.cc:294).
+    uint64_t resizeAndExtract(const ImageView& frame, double fx, double fy, std::vector<uint8_t>& resized,
+                              int& outWidth, int& outHeight, std::vector<KeyPoint>& keypoints,
+                              Mat8& descriptors)
+    {
+        if (frame.channels != 3) throw Error(SLAMFE_E_INVALID, "resizeAndExtract takes a BGR frame");
+        keypoints.resize((size_t)capacity_);
+        descriptors.data.resize((size_t)capacity_ * 32);
+        resized.resize((size_t)frame.width * frame.height * 3);
+        int n = 0;
+        uint64_t handle = 0;
+        check(slamfe_extract_scaled_bgr(ctx_, frame.data, frame.width, frame.height, frame.stride, fx, fy,
+                                        resized.data(), &outWidth, &outHeight,
+                                        reinterpret_cast<slamfe_keypoint*>(keypoints.data()),
+                                        descriptors.data.data(), capacity_, &n, &handle));
+        resized.resize((size_t)outWidth * outHeight * 3);
+        keypoints.resize((size_t)n);
+        descriptors.rows = n;
+        descriptors.cols = 32;
+        descriptors.data.resize((size_t)n * 32);
+        return handle;
+    }
+
     // matcher->knnMatch(descriptors1, descriptors2, matches, 2), Init.cc:131:
     // matches[i] holds up to k = 2 DMatch in (distance, trainIdx) order.
     void knnMatch(const Mat8& query, const Mat8& train, std::vector<std::vector<DMatch>>& matches, int k = 2)

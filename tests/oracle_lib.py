@@ -63,6 +63,18 @@ def bgr2gray(bgr):
     return out
 
 
+def resize_linear_8u(img, fx, fy):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    dw, dh = C.c_int(), C.c_int()
+    lib().orc_scaled_size(w, h, C.c_double(fx), C.c_double(fy), C.byref(dw), C.byref(dh))
+    out = np.empty((dh.value, dw.value) + (() if img.ndim == 2 else (cn,)), np.uint8)
+    lib().orc_resize_linear_8u(_p(img), w, h, w * cn, cn, C.c_double(fx), C.c_double(fy), _p(out),
+                               dw.value * cn)
+    return out
+
+
 def fast_score_map(img, thr):
     img = np.ascontiguousarray(img)
     h, w = img.shape

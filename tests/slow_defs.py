@@ -186,3 +186,42 @@ def search_by_projection(kp_xy, frame_desc, kp_idx, uv, point_desc, point_ids, r
             del rpoints[best]
             del ridx[best]
     return np.array(out, dtype=np.int32)
+
+
+def resize_linear_8u(src, fx, fy):
+    """cv::resize(src, dst, Size(), fx, fy), INTER_LINEAR on 8-bit pixels, written
+    from the definition: sample position (d + 0.5) / f - 0.5 in float32, weights
+    rounded to 1/2048, horizontal pass kept at 11 extra bits, vertical pass
+    ((b * (row >> 4)) >> 16 summed, + 2) >> 2."""
+    src = np.asarray(src)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    sh, sw, cn = src.shape
+    dw, dh = int(np.rint(sw * fx)), int(np.rint(sh * fy))
+
+    def taps(n_dst, n_src, f):
+        inv = 1.0 / f
+        pos = ((np.arange(n_dst, dtype=np.float64) + 0.5) * inv - 0.5).astype(np.float32)
+        i0 = np.floor(pos).astype(np.int64)
+        fr = (pos - i0.astype(np.float32)).astype(np.float32)
+        return i0, fr
+
+    ix, fxr = taps(dw, sw, fx)
+    fxr = np.where(ix < 0, np.float32(0), fxr)
+    ix = np.maximum(ix, 0)
+    over = ix >= sw - 1
+    fxr = np.where(over, np.float32(0), fxr)
+    ix = np.where(over, sw - 1, ix)
+    ix1 = np.minimum(ix + 1, sw - 1)
+    a1 = np.rint(fxr * np.float32(2048)).astype(np.int64)
+    a0 = np.rint((np.float32(1) - fxr) * np.float32(2048)).astype(np.int64)
+    iy, fyr = taps(dh, sh, fy)
+    b1 = np.rint(fyr * np.float32(2048)).astype(np.int64)
+    b0 = np.rint((np.float32(1) - fyr) * np.float32(2048)).astype(np.int64)
+    y0 = np.clip(iy, 0, sh - 1)
+    y1 = np.clip(iy + 1, 0, sh - 1)
+    s = src.astype(np.int64)
+    rows = s[:, ix, :] * a0[None, :, None] + s[:, ix1, :] * a1[None, :, None]  # [sh, dw, cn]
+    r0, r1 = rows[y0], rows[y1]
+    v = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)

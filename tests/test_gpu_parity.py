@@ -119,6 +119,40 @@ def test_extract_bgr_input(fe_orb, fe_ref):
         assert_frame_equal(f, kps, desc)
 
 
+@pytest.mark.parametrize("shape,seed", [((640, 480), 61), ((1241, 376), 62), ((333, 277), 63),
+                                        ((1280, 720), 64)])
+def test_extract_scaled_bgr_frame(fe_orb, fe_ref, shape, seed):
+    # Init.cc:103/126 resize(0.99) + Init.cc:74-79, against checker resize -> checker extract
+    w, h = shape
+    g = synth.textured_canvas(w, h, seed)
+    bgr = np.ascontiguousarray(np.stack([np.roll(g, 1, 0), g, np.roll(g, 2, 1)], axis=2))
+    want_frame = O.resize_linear_8u(bgr, 0.99, 0.99)
+    for fe in (fe_orb, fe_ref):
+        f, resized = fe.extract_scaled_bgr(bgr, 0.99, 0.99)
+        assert resized.shape == want_frame.shape
+        assert np.array_equal(resized, want_frame)
+        assert np.array_equal(fe.debug_read_level(0, 0, False), O.bgr2gray(want_frame))
+        kps, desc = O.extract(oracle_params(fe), want_frame)
+        assert len(kps) > 50
+        assert_frame_equal(f, kps, desc)
+
+
+def test_extract_scaled_bgr_other_factors_and_errors(fe_orb):
+    from slam_amd.frontend import SlamfeError
+    g = synth.textured_canvas(320, 240, 65)
+    bgr = np.ascontiguousarray(np.stack([g, np.roll(g, 3, 1), np.roll(g, 1, 0)], axis=2))
+    for fx, fy in ((1.0, 1.0), (0.75, 0.9), (0.6, 0.6)):
+        f, resized = fe_orb.extract_scaled_bgr(bgr, fx, fy)
+        want = O.resize_linear_8u(bgr, fx, fy)
+        assert np.array_equal(resized, want)
+        kps, desc = O.extract(oracle_params(fe_orb), want)
+        assert_frame_equal(f, kps, desc)
+    with pytest.raises(SlamfeError):
+        fe_orb.extract_scaled_bgr(bgr, 0.5, 0.5)   # exact halving is OpenCV's area path: not offered
+    with pytest.raises(SlamfeError):
+        fe_orb.extract_scaled_bgr(bgr, 1.5, 1.0)
+
+
 def test_extract_batch_equals_single_frames(fe_orb):
     frames = synth.frame_stream(640, 480, 4, seed=5)
     batch = fe_orb.extract_batch(list(frames))

@@ -170,6 +170,35 @@ def test_resize_exact_half_is_2x2_average():
     assert np.array_equal(got, want.astype(np.uint8))
 
 
+@pytest.mark.parametrize("shape,fx,fy", [((200, 300, 3), 0.99, 0.99), ((97, 131, 3), 0.99, 0.99),
+                                         ((64, 80, 1), 0.75, 0.9), ((50, 70, 3), 1.0, 1.0),
+                                         ((480, 640, 3), 0.99, 0.99)])
+def test_frame_resize_matches_slow_definition(shape, fx, fy):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = O.resize_linear_8u(img, fx, fy)
+    want = S.resize_linear_8u(img, fx, fy)
+    assert got.shape[:2] == want.shape[:2] == (round(shape[0] * fy), round(shape[1] * fx))
+    np.testing.assert_array_equal(got.reshape(want.shape), want)
+
+
+def test_frame_resize_known_answers():
+    # a constant frame stays constant, factor 1 is the identity, and a horizontal
+    # ramp stays monotone with its end values inside the source range
+    flat = np.full((60, 90, 3), 77, np.uint8)
+    assert (O.resize_linear_8u(flat, 0.99, 0.99) == 77).all()
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(O.resize_linear_8u(img, 1.0, 1.0), img)
+    ramp = np.tile(np.arange(200, dtype=np.uint8)[None, :, None], (30, 1, 3))
+    out = O.resize_linear_8u(ramp, 0.99, 0.99)
+    assert out.shape == (30, 198, 3)
+    assert (np.diff(out[:, :, 0].astype(int), axis=1) >= 0).all()
+    assert out[:, 0].min() == 0 and out[:, -1].max() <= 199
+    # the reference's frame sizes (main.cc: 1241x376 KITTI after 0.99)
+    assert O.resize_linear_8u(np.zeros((376, 1241, 3), np.uint8), 0.99, 0.99).shape == (372, 1229, 3)
+
+
 def test_pyramid_is_cumulative():
     img = synth.textured_canvas(200, 150, 15)
     lv = O.build_pyramid(img)
