@@ -39,6 +39,7 @@ from slam_amd.frontend import FrontEnd  # noqa: E402
 
 W, H, NFEAT, THR = 640, 480, 2000, 20
 HBM_PEAK_GBS = 8000.0
+VALU_PEAK_TOPS = 41.0  # measured: tools/ubench_valu.hip, v_xor + accumulating v_bcnt
 
 STAGES = {"pyramid": 1, "fast_blur": 2, "select": 3, "orient": 4, "describe": 6, "match": 7}
 
@@ -85,9 +86,45 @@ def cpu_baseline(frames, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 4 * len(frames):
             break
-    return {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames of the same 640x480 stream, extract + 1 match each, "
-                      f"{el:.1f} s, scalar C -O3, 1 thread"}
+    out = {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n} frames of the same 640x480 stream, extract + 1 match each, "
+                     f"{el:.1f} s, scalar C -O3, 1 thread"}
+    # matching alone: one thread, and query rows split over the host threads this
+    # process may use (OpenCV's batchDistance runs under parallel_for_)
+    from concurrent.futures import ThreadPoolExecutor
+    q = synth.random_descriptors(2000, 3, 5)
+    t = synth.random_descriptors(100000, 4, 6)
+    t0 = time.perf_counter()
+    O.match_knn2(q, t)
+    one = time.perf_counter() - t0
+    nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+    parts = [np.ascontiguousarray(q[ix]) for ix in np.array_split(np.arange(len(q)), nthr)]
+    with ThreadPoolExecutor(nthr) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda a: O.match_knn2(a, t), parts))
+        par = time.perf_counter() - t0
+    cm = len(q) * len(t) / 1e9
+    out["hamming_gcmps_1_thread"] = round(cm / one, 3)
+    out["hamming_gcmps_threads"] = round(cm / par, 3)
+    out["hamming_threads"] = nthr
+    return out
+
+
+def hbm_copy_ceiling(dev, nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate (read + write bytes per second): the practical
+    ceiling an HBM-streaming kernel can be held against."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2 * nbytes / (ms * 1e-3) / 1e9
 
 
 def main():
@@ -184,11 +221,19 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": roof_bytes,
-                "avg_launch_ms": round(stage_ms[hbm_stage], 5)}
+                "avg_launch_ms": round(stage_ms[hbm_stage], 5),
+                "measured_copy_ceiling_GBps": round(hbm_copy_ceiling(dev), 1)}
 
     # Hamming comparisons/s of the match kernel inside the frame pipeline
     cmps = float((all_counts[:-1] * all_counts[1:]).sum())
-    hamming = {"frame_pairs_gcmps": round(cmps / (stage_ms["match"] * 1e-3) / 1e9, 2)}
+    gc = cmps / (stage_ms["match"] * 1e-3) / 1e9
+    # integer-VALU roofline of the match kernel: 16 lane-ops (8 xor + 8 popcount-
+    # accumulate) per 256-bit comparison against the measured issue ceiling of
+    # tools/ubench_valu.hip (41.0 T lane-ops/s on MI355X)
+    hamming = {"frame_pairs_gcmps": round(gc, 2),
+               "valu_roofline": {"lane_ops_per_cmp": 16, "achieved_Tops": round(gc * 16 / 1e3, 2),
+                                 "peak_Tops": VALU_PEAK_TOPS,
+                                 "frac": round(gc * 16 / 1e3 / VALU_PEAK_TOPS, 4)}}
 
     # relocalisation: 2000 queries against a 1M-row map sharded over the ranks
     if not args.no_reloc:
@@ -230,6 +275,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rel = float(t.item())
         hamming["reloc_2000x1M_gcmps"] = round(NQ * NT * R / rel / 1e9, 2)
+        hamming["reloc_valu_frac"] = round(NQ * NT * R / rel / 1e12 * 16 / (VALU_PEAK_TOPS * world), 4)
         hamming["reloc_ms_per_query_set"] = round(rel / R * 1e3, 4)
         hamming["reloc_scaling"] = "strong (map rows split over ranks, RCCL all-gather of top-2 keys)"
 

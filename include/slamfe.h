@@ -211,6 +211,34 @@ int slamfe_search_by_projection(slamfe_ctx* ctx, uint64_t frame, const int32_t* 
                                 const float* uv, const int32_t* point_ids, int R, float radius,
                                 int max_hamming, int32_t* matched_point_id);
 
+/* Mirror of the map points' coordinates: Point::Point(id, x, y, z, ...)
+ * (keyframe.cc:6, created at Init.cc:296) and Point::setCoords after bundle
+ * adjustment (keyframe.cc:15-25, optimizer.cc:145).  Row point_ids[i] of the
+ * device table receives xyz[3*i .. 3*i+2].  Ids as for slamfe_map_put. */
+int slamfe_map_put_xyz(slamfe_ctx* ctx, const int32_t* point_ids, const float* xyz, int n);
+
+/* Replaces the reprojection loop of Init.cc:203-218 over map points 0..npoints-1
+ * (the reference's map index equals Point::id, Init.cc:296): depth gate against
+ * th (Init.cc:205), pt = K4x4 * pose.inv() * X (Init.cc:206-208), the two
+ * homogeneous divisions (Init.cc:211, 213) and the image gate 0 < u < W,
+ * 0 < v < H (Init.cc:214-215).  pose: keyframe->getPose(), 4x4 row-major float;
+ * K: 3x3 row-major float (Init.cc:95-99); th: pose(2,3) (Init.cc:192).  The
+ * visible points stay on the device for slamfe_search_by_projection_visible;
+ * uv (rPoints, 2 floats each) and point_idx (rPointsIdx), if not NULL, receive
+ * them in ascending order, at most cap; *n_visible their number.  A singular
+ * pose is SLAMFE_E_INVALID.  Float arithmetic follows OpenCV's small-matrix
+ * code: float products summed left to right, LU inverse in float, division by s
+ * as multiplication by the float value of 1.0/s. */
+int slamfe_reproject(slamfe_ctx* ctx, const float* pose, const float* K, float th, float W, float H,
+                     int npoints, float* uv, int32_t* point_idx, int cap, int* n_visible);
+
+/* Init.cc:229-259 as slamfe_search_by_projection, over the visible set the last
+ * slamfe_reproject call left on the device (no host round trip of rPoints /
+ * rPointsIdx); matched_point_id[i] is the matched point's id or -1. */
+int slamfe_search_by_projection_visible(slamfe_ctx* ctx, uint64_t frame_handle, const int32_t* kp_idx,
+                                        int n_inl, float radius, int max_hamming,
+                                        int32_t* matched_point_id);
+
 /* Wait for everything queued on the context's stream (no counterpart in the
  * reference, whose OpenCV calls are synchronous). */
 int slamfe_sync(slamfe_ctx* ctx);

@@ -636,3 +636,92 @@ void orc_search_by_projection(const float* kp_xy, const uint8_t* frame_desc, con
     }
     free(live);
 }
+
+
+/* ---------------------------------------------------------------------------
+ * Map-point reprojection, Init.cc:203-218.
+ *
+ * keyframe->getPose().inv() (Init.cc:206): cv::invert with DECOMP_LU on a 4x4
+ * CV_32F matrix: Gaussian elimination with partial pivoting in float on a copy
+ * of the matrix and an identity right-hand side, the pivot's reciprocal kept in
+ * place of the pivot, back-substitution multiplying by it.  A pivot below
+ * 10*FLT_EPSILON makes the matrix singular: OpenCV then returns all zeros.
+ * K4x4 * kf * pt (Init.cc:208) is evaluated left to right; OpenCV's small-matrix
+ * product sums the four float products of a row left to right in float.
+ * pt /= s (Init.cc:211, 213) scales by the float value of 1.0/s computed in
+ * double.  No fused multiply-add anywhere (-ffp-contract=off).
+ * ------------------------------------------------------------------------- */
+int orc_invert4x4(const float* src, float* dst)
+{
+    float A[16], B[16];
+    memcpy(A, src, sizeof A);
+    for (int i = 0; i < 16; ++i) B[i] = (i % 5 == 0) ? 1.f : 0.f;
+    const float eps = FLT_EPSILON * 10;
+    for (int i = 0; i < 4; ++i) {
+        int k = i;
+        for (int j = i + 1; j < 4; ++j)
+            if (fabsf(A[j * 4 + i]) > fabsf(A[k * 4 + i])) k = j;
+        if (fabsf(A[k * 4 + i]) < eps) {
+            memset(dst, 0, 16 * sizeof(float));
+            return 0;
+        }
+        if (k != i) {
+            for (int j = i; j < 4; ++j) { float t = A[i * 4 + j]; A[i * 4 + j] = A[k * 4 + j]; A[k * 4 + j] = t; }
+            for (int j = 0; j < 4; ++j) { float t = B[i * 4 + j]; B[i * 4 + j] = B[k * 4 + j]; B[k * 4 + j] = t; }
+        }
+        float d = -1 / A[i * 4 + i];
+        for (int j = i + 1; j < 4; ++j) {
+            float alpha = A[j * 4 + i] * d;
+            for (int c = i + 1; c < 4; ++c) A[j * 4 + c] += alpha * A[i * 4 + c];
+            for (int c = 0; c < 4; ++c) B[j * 4 + c] += alpha * B[i * 4 + c];
+        }
+        A[i * 4 + i] = -d;
+    }
+    for (int i = 3; i >= 0; --i)
+        for (int j = 0; j < 4; ++j) {
+            float sum = B[i * 4 + j];
+            for (int c = i + 1; c < 4; ++c) sum -= A[i * 4 + c] * B[c * 4 + j];
+            B[i * 4 + j] = sum * A[i * 4 + i];
+        }
+    memcpy(dst, B, sizeof B);
+    return 1;
+}
+
+void orc_matmul4x4(const float* a, const float* b, float* d)
+{
+    float out[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            out[i * 4 + j] = a[i * 4] * b[j] + a[i * 4 + 1] * b[4 + j] + a[i * 4 + 2] * b[8 + j] +
+                             a[i * 4 + 3] * b[12 + j];
+    memcpy(d, out, sizeof out);
+}
+
+int orc_reproject(const float* pose, const float* K, const float* xyz, int npoints, float th, float W,
+                  float H, float* uv, int32_t* idx)
+{
+    float kf[16], K4[16], M[16];
+    orc_invert4x4(pose, kf);
+    for (int i = 0; i < 16; ++i) K4[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) K4[r * 4 + c] = K[r * 3 + c];
+    orc_matmul4x4(K4, kf, M);
+    int n = 0;
+    for (int i = 0; i < npoints; ++i) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (z < th || fabs((double)(z - th)) > 20) continue; /* Init.cc:205 */
+        float p[4];
+        for (int r = 0; r < 4; ++r)
+            p[r] = M[r * 4] * x + M[r * 4 + 1] * y + M[r * 4 + 2] * z + M[r * 4 + 3] * 1.f;
+        float s = (float)(1. / (double)p[3]); /* Init.cc:211 */
+        for (int r = 0; r < 4; ++r) p[r] = p[r] * s;
+        s = (float)(1. / (double)p[2]); /* Init.cc:213 */
+        for (int r = 0; r < 4; ++r) p[r] = p[r] * s;
+        if (p[0] <= 0 || p[0] >= W || p[1] <= 0 || p[1] >= H) continue; /* Init.cc:214-215 */
+        idx[n] = i;
+        uv[2 * n] = p[0];
+        uv[2 * n + 1] = p[1];
+        ++n;
+    }
+    return n;
+}

@@ -108,6 +108,16 @@ void orc_search_by_projection(const float* kp_xy, const uint8_t* frame_desc, con
 
 int orc_hamming256(const uint8_t* a, const uint8_t* b);
 
+/* The reprojection loop of Init.cc:203-218: pose = keyframe->getPose() (4x4
+ * row-major float), K (3x3 row-major float), xyz = getCoords() of the map points
+ * in map order.  Writes the visible points (rPoints as uv pairs, rPointsIdx) in
+ * ascending order and returns their number.  orc_invert4x4 returns 0 and a zero
+ * matrix for a singular input, as cv::invert does. */
+int orc_invert4x4(const float* src, float* dst);
+void orc_matmul4x4(const float* a, const float* b, float* d);
+int orc_reproject(const float* pose, const float* K, const float* xyz, int npoints, float th, float W,
+                  float H, float* uv, int32_t* idx);
+
 #ifdef __cplusplus
 }
 #endif

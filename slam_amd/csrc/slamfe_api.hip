@@ -13,12 +13,15 @@
 //   map_desc        [map_capacity][32]          mirror of Point::desc
 #include <hip/hip_runtime.h>
 
+#include <float.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <cmath>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "slamfe.h"
@@ -79,6 +82,11 @@ struct slamfe_ctx {
     uint8_t* map_desc = nullptr;
     Scratch pj_idx, pj_uv, pj_ids, pj_cand, pj_candn, pj_matched;
     Scratch ing_taps, ing_bgr;
+    // reprojection: coordinates table (row = Point::id), scratch, and the visible
+    // set the last slamfe_reproject call left on the device
+    float* map_xyz = nullptr;
+    Scratch rp_uv_all, rp_mask, rp_off, rp_total, vis_uv, vis_idx;
+    int vis_count = -1;
 };
 
 namespace {
@@ -412,7 +420,8 @@ void slamfe_destroy(slamfe_ctx* c)
                     c->kp_count, c->kps, c->desc, c->kp_mom, c->kp_rot, c->match_out, c->map_desc, c->match_part.p,
                     c->match_q.p, c->match_t.p, c->match_o.p, c->pj_idx.p, c->pj_uv.p,
                     c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p, c->ing_taps.p,
-                    c->ing_bgr.p};
+                    c->ing_bgr.p, c->map_xyz, c->rp_uv_all.p, c->rp_mask.p, c->rp_off.p, c->rp_total.p,
+                    c->vis_uv.p, c->vis_idx.p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -503,6 +512,8 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     if (p.map_capacity > 0) {
         HIPCHK(c, hipMalloc(&c->map_desc, (size_t)p.map_capacity * 32));
         HIPCHK(c, hipMemset(c->map_desc, 0, (size_t)p.map_capacity * 32));
+        HIPCHK(c, hipMalloc(&c->map_xyz, (size_t)p.map_capacity * 12));
+        HIPCHK(c, hipMemset(c->map_xyz, 0, (size_t)p.map_capacity * 12));
     }
     HIPCHK(c, hipDeviceSynchronize());
     return SLAMFE_OK;
@@ -828,13 +839,14 @@ int slamfe_map_put(slamfe_ctx* c, const int32_t* point_ids, const uint8_t* desc3
     return SLAMFE_OK;
 }
 
-int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n_inl,
-                                const float* uv, const int32_t* point_ids, int R, float radius,
-                                int max_hamming, int32_t* matched_point_id)
+namespace {
+
+// The search of Init.cc:229-259 over a visible set that is either uploaded from
+// the host (uv, point_ids) or already on the device (d_uv, d_ids).
+int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n_inl, const float* uv,
+                     const int32_t* point_ids, const float* d_uv, const int32_t* d_ids, int R,
+                     float radius, int max_hamming, int32_t* matched_point_id)
 {
-    if (!c || n_inl < 0 || R < 0 || (n_inl > 0 && (!kp_idx || !matched_point_id)) ||
-        (R > 0 && (!uv || !point_ids)))
-        return SLAMFE_E_INVALID;
     if (R > SLAMFE_PROJ_MAX_POINTS)
         return fail(c, SLAMFE_E_CAPACITY, "%d visible points; at most %d", R, SLAMFE_PROJ_MAX_POINTS);
     HIPCHK(c, hipSetDevice(c->p.device_id));
@@ -845,10 +857,6 @@ int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp
         for (int i = 0; i < n_inl; ++i) matched_point_id[i] = -1;
         return SLAMFE_OK;
     }
-    for (int j = 0; j < R; ++j)
-        if (point_ids[j] < 0 || point_ids[j] >= c->p.map_capacity)
-            return fail(c, SLAMFE_E_INVALID, "point id %d outside map_capacity %d", point_ids[j],
-                        c->p.map_capacity);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->kp_count + slot, sizeof(int32_t), hipMemcpyDeviceToHost,
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -860,32 +868,182 @@ int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp
                         kp_idx[i], nkp);
     int rc;
     if ((rc = grow(c, c->pj_idx, (size_t)n_inl * 4))) return rc;
-    if ((rc = grow(c, c->pj_uv, (size_t)R * 8))) return rc;
-    if ((rc = grow(c, c->pj_ids, (size_t)R * 4))) return rc;
     if ((rc = grow(c, c->pj_cand, (size_t)n_inl * SLAMFE_PROJ_K * 4))) return rc;
     if ((rc = grow(c, c->pj_candn, (size_t)n_inl * 4))) return rc;
     if ((rc = grow(c, c->pj_matched, (size_t)n_inl * 4))) return rc;
+    if (!d_uv) {
+        if ((rc = grow(c, c->pj_uv, (size_t)R * 8))) return rc;
+        if ((rc = grow(c, c->pj_ids, (size_t)R * 4))) return rc;
+    }
     hipStream_t s = c->stream;
     const size_t o_idx = 0, o_uv = align256((size_t)n_inl * 4), o_ids = o_uv + align256((size_t)R * 8),
                  o_out = o_ids + align256((size_t)R * 4);
     if ((rc = pin_reserve(c, o_out + (size_t)n_inl * 4))) return rc;
     memcpy(c->h_pin + o_idx, kp_idx, (size_t)n_inl * 4);
-    memcpy(c->h_pin + o_uv, uv, (size_t)R * 8);
-    memcpy(c->h_pin + o_ids, point_ids, (size_t)R * 4);
     HIPCHK(c, hipMemcpyAsync(c->pj_idx.p, c->h_pin + o_idx, (size_t)n_inl * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->pj_uv.p, c->h_pin + o_uv, (size_t)R * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->pj_ids.p, c->h_pin + o_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    if (!d_uv) {
+        memcpy(c->h_pin + o_uv, uv, (size_t)R * 8);
+        memcpy(c->h_pin + o_ids, point_ids, (size_t)R * 4);
+        HIPCHK(c, hipMemcpyAsync(c->pj_uv.p, c->h_pin + o_uv, (size_t)R * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->pj_ids.p, c->h_pin + o_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
+        d_uv = (const float*)c->pj_uv.p;
+        d_ids = (const int32_t*)c->pj_ids.p;
+    }
     KCHK(c, slamfe_launch_projection(s, c->kps + (size_t)slot * c->max_kp,
                                      c->desc + (size_t)slot * c->max_kp * 32, nkp,
-                                     (const int32_t*)c->pj_idx.p, n_inl, (const float*)c->pj_uv.p,
-                                     (const int32_t*)c->pj_ids.p, R, c->map_desc, radius, max_hamming,
-                                     (uint32_t*)c->pj_cand.p, (int32_t*)c->pj_candn.p,
-                                     (int32_t*)c->pj_matched.p));
+                                     (const int32_t*)c->pj_idx.p, n_inl, d_uv, d_ids, R, c->map_desc,
+                                     radius, max_hamming, (uint32_t*)c->pj_cand.p,
+                                     (int32_t*)c->pj_candn.p, (int32_t*)c->pj_matched.p));
     HIPCHK(c, hipMemcpyAsync(c->h_pin + o_out, c->pj_matched.p, (size_t)n_inl * 4,
                              hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     memcpy(matched_point_id, c->h_pin + o_out, (size_t)n_inl * 4);
     return SLAMFE_OK;
+}
+
+// cv::invert(DECOMP_LU) on a 4x4 float matrix: elimination with partial pivoting
+// on [A | I] in float, the pivot's reciprocal kept and used by the
+// back-substitution.  Returns false for a singular matrix.
+bool invert4x4(const float* src, float* dst)
+{
+    float A[4][4], B[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            A[i][j] = src[i * 4 + j];
+            B[i][j] = i == j ? 1.f : 0.f;
+        }
+    for (int i = 0; i < 4; ++i) {
+        int k = i;
+        for (int j = i + 1; j < 4; ++j)
+            if (std::fabs(A[j][i]) > std::fabs(A[k][i])) k = j;
+        if (std::fabs(A[k][i]) < FLT_EPSILON * 10) return false;
+        if (k != i)
+            for (int j = 0; j < 4; ++j) {
+                std::swap(A[i][j], A[k][j]);
+                std::swap(B[i][j], B[k][j]);
+            }
+        const float d = -1 / A[i][i];
+        for (int j = i + 1; j < 4; ++j) {
+            const float alpha = A[j][i] * d;
+            for (int q = i + 1; q < 4; ++q) A[j][q] += alpha * A[i][q];
+            for (int q = 0; q < 4; ++q) B[j][q] += alpha * B[i][q];
+        }
+        A[i][i] = -d;
+    }
+    for (int i = 3; i >= 0; --i)
+        for (int j = 0; j < 4; ++j) {
+            float sum = B[i][j];
+            for (int q = i + 1; q < 4; ++q) sum -= A[i][q] * B[q][j];
+            dst[i * 4 + j] = B[i][j] = sum * A[i][i];
+        }
+    return true;
+}
+
+} // namespace
+
+int slamfe_search_by_projection(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n_inl,
+                                const float* uv, const int32_t* point_ids, int R, float radius,
+                                int max_hamming, int32_t* matched_point_id)
+{
+    if (!c || n_inl < 0 || R < 0 || (n_inl > 0 && (!kp_idx || !matched_point_id)) ||
+        (R > 0 && (!uv || !point_ids)))
+        return SLAMFE_E_INVALID;
+    for (int j = 0; j < R; ++j)
+        if (point_ids[j] < 0 || point_ids[j] >= c->p.map_capacity)
+            return fail(c, SLAMFE_E_INVALID, "point id %d outside map_capacity %d", point_ids[j],
+                        c->p.map_capacity);
+    return search_projected(c, frame, kp_idx, n_inl, uv, point_ids, nullptr, nullptr, R, radius,
+                            max_hamming, matched_point_id);
+}
+
+int slamfe_map_put_xyz(slamfe_ctx* c, const int32_t* point_ids, const float* xyz, int n)
+{
+    if (!c || n < 0 || (n > 0 && (!point_ids || !xyz))) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    for (int i = 0; i < n; ++i)
+        if (point_ids[i] < 0 || point_ids[i] >= c->p.map_capacity)
+            return fail(c, SLAMFE_E_CAPACITY, "point id %d outside map_capacity %d", point_ids[i],
+                        c->p.map_capacity);
+    if (n == 0) return SLAMFE_OK;
+    int rc = pin_reserve(c, (size_t)n * 12);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin, xyz, (size_t)n * 12);
+    int i = 0;
+    while (i < n) { // runs of consecutive ids go in one transfer each
+        int j = i + 1;
+        while (j < n && point_ids[j] == point_ids[j - 1] + 1) ++j;
+        HIPCHK(c, hipMemcpyAsync(c->map_xyz + (size_t)point_ids[i] * 3, c->h_pin + (size_t)i * 12,
+                                 (size_t)(j - i) * 12, hipMemcpyHostToDevice, c->stream));
+        i = j;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->vis_count = -1;
+    return SLAMFE_OK;
+}
+
+int slamfe_reproject(slamfe_ctx* c, const float* pose, const float* K, float th, float W, float H,
+                     int npoints, float* uv, int32_t* point_idx, int cap, int* n_visible)
+{
+    if (!c || !pose || !K || npoints < 0) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    if (npoints > c->p.map_capacity)
+        return fail(c, SLAMFE_E_CAPACITY, "%d points; map_capacity is %d", npoints, c->p.map_capacity);
+    c->vis_count = -1;
+    float kf[16], M[16];
+    if (!invert4x4(pose, kf)) return fail(c, SLAMFE_E_INVALID, "the keyframe pose is singular");
+    // K4x4 * kf with K4x4 = [K 0; 0 1]; four float products summed left to right
+    for (int r = 0; r < 4; ++r)
+        for (int q = 0; q < 4; ++q) {
+            float k4[4] = {r < 3 ? K[r * 3] : 0.f, r < 3 ? K[r * 3 + 1] : 0.f, r < 3 ? K[r * 3 + 2] : 0.f,
+                           r < 3 ? 0.f : 1.f};
+            M[r * 4 + q] = k4[0] * kf[q] + k4[1] * kf[4 + q] + k4[2] * kf[8 + q] + k4[3] * kf[12 + q];
+        }
+    if (npoints == 0) {
+        c->vis_count = 0;
+        if (n_visible) *n_visible = 0;
+        return SLAMFE_OK;
+    }
+    const size_t nwaves = ((size_t)npoints + 255) / 256 * 4;
+    int rc;
+    if ((rc = grow(c, c->rp_uv_all, (size_t)npoints * 8))) return rc;
+    if ((rc = grow(c, c->rp_mask, nwaves * 8))) return rc;
+    if ((rc = grow(c, c->rp_off, nwaves * 4))) return rc;
+    if ((rc = grow(c, c->rp_total, 4))) return rc;
+    if ((rc = grow(c, c->vis_uv, (size_t)npoints * 8))) return rc;
+    if ((rc = grow(c, c->vis_idx, (size_t)npoints * 4))) return rc;
+    hipStream_t s = c->stream;
+    KCHK(c, slamfe_launch_reproject(s, c->map_xyz, npoints, M, th, W, H, (float*)c->rp_uv_all.p,
+                                    (uint64_t*)c->rp_mask.p, (int32_t*)c->rp_off.p,
+                                    (int32_t*)c->rp_total.p, (float*)c->vis_uv.p, (int32_t*)c->vis_idx.p));
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->rp_total.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int R = c->h_cnt[0];
+    c->vis_count = R;
+    if (n_visible) *n_visible = R;
+    if (!uv && !point_idx) return SLAMFE_OK;
+    if (R > cap) return fail(c, SLAMFE_E_CAPACITY, "%d visible points exceed the caller's capacity %d", R, cap);
+    if (R == 0) return SLAMFE_OK;
+    if ((rc = pin_reserve(c, (size_t)R * 12))) return rc;
+    if (uv) HIPCHK(c, hipMemcpyAsync(c->h_pin, c->vis_uv.p, (size_t)R * 8, hipMemcpyDeviceToHost, s));
+    if (point_idx)
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + (size_t)R * 8, c->vis_idx.p, (size_t)R * 4,
+                                 hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (uv) memcpy(uv, c->h_pin, (size_t)R * 8);
+    if (point_idx) memcpy(point_idx, c->h_pin + (size_t)R * 8, (size_t)R * 4);
+    return SLAMFE_OK;
+}
+
+int slamfe_search_by_projection_visible(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n_inl,
+                                        float radius, int max_hamming, int32_t* matched_point_id)
+{
+    if (!c || n_inl < 0 || (n_inl > 0 && (!kp_idx || !matched_point_id))) return SLAMFE_E_INVALID;
+    if (c->vis_count < 0)
+        return fail(c, SLAMFE_E_INVALID, "no visible set on the device: call slamfe_reproject first");
+    return search_projected(c, frame, kp_idx, n_inl, nullptr, nullptr, (const float*)c->vis_uv.p,
+                            (const int32_t*)c->vis_idx.p, c->vis_count, radius, max_hamming,
+                            matched_point_id);
 }
 
 int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, float* avg_ms)

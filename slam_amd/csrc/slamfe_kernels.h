@@ -52,6 +52,9 @@ int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const ui
                              const int32_t* kp_idx, int n_inl, const float* uv,
                              const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
                              int max_hamming, uint32_t* cand, int32_t* cand_n, int32_t* matched);
+int slamfe_launch_reproject(hipStream_t s, const float* xyz, int npoints, const float* M16, float th,
+                            float W, float H, float* uv_all, uint64_t* wave_mask, int32_t* wave_off,
+                            int32_t* total, float* vis_uv, int32_t* vis_idx);
 int slamfe_kernels_init(size_t sort_lds_bytes);
 
 #endif

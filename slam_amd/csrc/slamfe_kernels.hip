@@ -1551,6 +1551,116 @@ int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const ui
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Map-point reprojection, Init.cc:203-218.  M = K4x4 * inverse(pose) is formed
+// once on the host (the reference recomputes the same inverse for every point);
+// the three kernels apply the depth gate, project, apply the image gate and
+// compact the survivors in ascending map order.
+//   k_reproject_test    one lane per point: gates + projection, ballot per wave
+//   k_reproject_scan    one workgroup: exclusive scan of the per-wave counts
+//   k_reproject_scatter ordered scatter of (u, v) and the point index
+// Float arithmetic: products and sums in float, left to right, no fused
+// multiply-add; pt /= s multiplies by the float value of 1.0/s taken in double.
+// ---------------------------------------------------------------------------
+struct slamfe_proj_mat { float m[16]; };
+
+__global__ __launch_bounds__(256) void k_reproject_test(const float* __restrict__ xyz, int npoints,
+                                                        slamfe_proj_mat M, float th, float W, float H,
+                                                        float2* __restrict__ uv_all,
+                                                        uint64_t* __restrict__ wave_mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool vis = false;
+    float2 out = make_float2(0.f, 0.f);
+    if (i < npoints) {
+        const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+        if (!(z < th || fabs((double)(z - th)) > 20.0)) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p[r] = M.m[r * 4] * x + M.m[r * 4 + 1] * y + M.m[r * 4 + 2] * z + M.m[r * 4 + 3] * 1.f;
+            float sc = (float)(1.0 / (double)p[3]);
+            p[0] = p[0] * sc;
+            p[1] = p[1] * sc;
+            p[2] = p[2] * sc;
+            sc = (float)(1.0 / (double)p[2]);
+            p[0] = p[0] * sc;
+            p[1] = p[1] * sc;
+            vis = !(p[0] <= 0.f || p[0] >= W || p[1] <= 0.f || p[1] >= H);
+            out = make_float2(p[0], p[1]);
+        }
+        uv_all[i] = out;
+    }
+    const uint64_t b = __ballot(vis);
+    if ((threadIdx.x & 63) == 0) wave_mask[(blockIdx.x * 256 + threadIdx.x) >> 6] = b;
+}
+
+__global__ __launch_bounds__(1024) void k_reproject_scan(const uint64_t* __restrict__ wave_mask, int nwaves,
+                                                         int32_t* __restrict__ wave_off,
+                                                         int32_t* __restrict__ total)
+{
+    __shared__ int part[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < nwaves; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nwaves ? __popcll(wave_mask[i]) : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) part[wv] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int k = 0; k < wv; ++k) before += part[k];
+        if (i < nwaves) wave_off[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_reproject_scatter(const float2* __restrict__ uv_all, int npoints,
+                                                           const uint64_t* __restrict__ wave_mask,
+                                                           const int32_t* __restrict__ wave_off,
+                                                           float2* __restrict__ vis_uv,
+                                                           int32_t* __restrict__ vis_idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npoints) return;
+    const uint64_t m = wave_mask[i >> 6];
+    const int lane = i & 63;
+    if (!((m >> lane) & 1)) return;
+    const int pos = wave_off[i >> 6] + __popcll(m & ((1ull << lane) - 1));
+    vis_uv[pos] = uv_all[i];
+    vis_idx[pos] = i;
+}
+
+int slamfe_launch_reproject(hipStream_t s, const float* xyz, int npoints, const float* M16, float th,
+                            float W, float H, float* uv_all, uint64_t* wave_mask, int32_t* wave_off,
+                            int32_t* total, float* vis_uv, int32_t* vis_idx)
+{
+    if (npoints <= 0) return 0;
+    slamfe_proj_mat M;
+    for (int i = 0; i < 16; ++i) M.m[i] = M16[i];
+    const int nblk = (npoints + 255) / 256, nwaves = nblk * 4;
+    hipLaunchKernelGGL(k_reproject_test, dim3(nblk), dim3(256), 0, s, xyz, npoints, M, th, W, H,
+                       reinterpret_cast<float2*>(uv_all), wave_mask);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reproject_scan, dim3(1), dim3(1024), 0, s, wave_mask, nwaves, wave_off, total);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reproject_scatter, dim3(nblk), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(uv_all), npoints, wave_mask, wave_off,
+                       reinterpret_cast<float2*>(vis_uv), vis_idx);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // Raise the dynamic-LDS limits of the two kernels that may need more than the
 // default 64 KiB (4K-wide frames; very large local maps).
 int slamfe_kernels_init(size_t sort_lds_bytes)

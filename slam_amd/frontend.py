@@ -245,6 +245,43 @@ class FrontEnd:
             out.ctypes.data))
         return out[:len(kp_idx)]
 
+    def map_put_xyz(self, point_ids, xyz):
+        """Mirror of ``Point::getCoords`` (keyframe.cc:6, 15-25) by point id."""
+        ids = np.ascontiguousarray(point_ids, np.int32)
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        if len(ids) != len(x):
+            raise ValueError("one coordinate triple per point id")
+        self._check(self._lib.slamfe_map_put_xyz(self._ctx, ids.ctypes.data, x.ctypes.data, len(ids)))
+
+    def reproject(self, pose, K, th: float, W: float, H: float, npoints: int, download: bool = True):
+        """The reprojection loop of Init.cc:203-218 over map points 0..npoints-1.
+        Returns (uv [R,2] f32, point index [R] i32) in ascending order, or just R
+        when ``download`` is false; the visible set stays on the device."""
+        pose = np.ascontiguousarray(pose, np.float32).reshape(4, 4)
+        K = np.ascontiguousarray(K, np.float32).reshape(3, 3)
+        n = C.c_int32()
+        if not download:
+            self._check(self._lib.slamfe_reproject(self._ctx, pose.ctypes.data, K.ctypes.data,
+                                                   C.c_float(th), C.c_float(W), C.c_float(H), npoints,
+                                                   None, None, 0, C.byref(n)))
+            return n.value
+        uv = np.zeros((max(npoints, 1), 2), np.float32)
+        idx = np.zeros(max(npoints, 1), np.int32)
+        self._check(self._lib.slamfe_reproject(self._ctx, pose.ctypes.data, K.ctypes.data,
+                                               C.c_float(th), C.c_float(W), C.c_float(H), npoints,
+                                               uv.ctypes.data, idx.ctypes.data, npoints, C.byref(n)))
+        return uv[:n.value].copy(), idx[:n.value].copy()
+
+    def search_by_projection_visible(self, frame: Frame, kp_idx, radius: float = 32.0,
+                                     max_hamming: int = 128) -> np.ndarray:
+        """Init.cc:229-259 over the visible set left on the device by ``reproject``."""
+        kp_idx = np.ascontiguousarray(kp_idx, np.int32)
+        out = np.full(max(len(kp_idx), 1), -2, np.int32)
+        self._check(self._lib.slamfe_search_by_projection_visible(
+            self._ctx, C.c_uint64(int(frame.handle)), kp_idx.ctypes.data, len(kp_idx),
+            C.c_float(radius), max_hamming, out.ctypes.data))
+        return out[:len(kp_idx)]
+
     def debug_read_level(self, frame_in_batch: int, level: int, blurred: bool) -> np.ndarray:
         """Test hook: a pyramid level of the most recent extraction."""
         cap = self.params.max_width * self.params.max_height

@@ -161,6 +161,45 @@ public:
         return handle;
     }
 
+    // Mirror of Point::getCoords() by Point::id (keyframe.cc:6, 15-25, optimizer.cc:145).
+    void mapPutXyz(int pointId, float x, float y, float z)
+    {
+        const float xyz[3] = {x, y, z};
+        check(slamfe_map_put_xyz(ctx_, &pointId, xyz, 1));
+    }
+    void mapPutXyz(const std::vector<int>& pointIds, const std::vector<float>& xyz)
+    {
+        if (xyz.size() != pointIds.size() * 3) throw Error(SLAMFE_E_INVALID, "three coordinates per point id");
+        check(slamfe_map_put_xyz(ctx_, pointIds.data(), xyz.data(), (int)pointIds.size()));
+    }
+
+    // The reprojection loop of Init.cc:203-218 over map points 0..npoints-1:
+    // fills rPoints (u, v pairs) and rPointsIdx in ascending order; the visible
+    // set also stays on the device for searchByProjectionVisible.
+    // pose16: keyframe->getPose() row-major, K9: the 3x3 intrinsics row-major.
+    int reproject(const float* pose16, const float* K9, float th, float W, float H, int npoints,
+                  std::vector<float>& rPointsUv, std::vector<int>& rPointsIdx)
+    {
+        rPointsUv.resize((size_t)npoints * 2);
+        rPointsIdx.resize((size_t)npoints);
+        int n = 0;
+        check(slamfe_reproject(ctx_, pose16, K9, th, W, H, npoints, rPointsUv.data(), rPointsIdx.data(),
+                               npoints, &n));
+        rPointsUv.resize((size_t)n * 2);
+        rPointsIdx.resize((size_t)n);
+        return n;
+    }
+
+    // Init.cc:229-259 over the visible set of the last reproject() call.
+    std::vector<int> searchByProjectionVisible(uint64_t frameHandle, const std::vector<int>& inlierTrainIdx,
+                                               float radius = 32.f, int maxHamming = 128)
+    {
+        std::vector<int> hit(inlierTrainIdx.size(), -1);
+        check(slamfe_search_by_projection_visible(ctx_, frameHandle, inlierTrainIdx.data(),
+                                                  (int)inlierTrainIdx.size(), radius, maxHamming, hit.data()));
+        return hit;
+    }
+
     // matcher->knnMatch(descriptors1, descriptors2, matches, 2), Init.cc:131:
     // matches[i] holds up to k = 2 DMatch in (distance, trainIdx) order.
     void knnMatch(const Mat8& query, const Mat8& train, std::vector<std::vector<DMatch>>& matches, int k = 2)

@@ -175,3 +175,39 @@ def local_map(frame_desc: np.ndarray, frame_xy: np.ndarray, npoints: int, w: int
         v[half] = frame_xy[src, 1] + dv
     uv = np.stack([u, v], axis=1).astype(np.float32)
     return np.ascontiguousarray(uv), np.ascontiguousarray(desc)
+
+
+def camera_scene(npoints: int, w: int, h: int, seed: int = 7):
+    """A keyframe pose, the intrinsics of Init.cc:90-99 (f = 984, principal point
+    at the image centre) and npoints map points: most of them in front of the
+    camera inside a frustum somewhat wider than the image, the rest behind it,
+    far away or off to the side, so that every gate of Init.cc:205,214-215 fires.
+    Returns (pose 4x4 f32, K 3x3 f32, xyz [n,3] f32, th)."""
+    idx = np.arange(npoints, dtype=np.uint64)
+
+    def uni(stream):  # uniform in [0, 1)
+        return (hash_u64(seed, stream, idx) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+    a = np.array([(int(hash_u64(seed, 90 + i, np.uint64(0))) >> 40) / float(1 << 24) - 0.5 for i in range(6)])
+    rx, ry, rz = a[:3] * 0.2
+    cx_, sx_, cy_, sy_, cz_, sz_ = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx_, -sx_], [0, sx_, cx_]])
+    Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+    Rz = np.array([[cz_, -sz_, 0], [sz_, cz_, 0], [0, 0, 1]])
+    pose = np.eye(4)
+    pose[:3, :3] = Rz @ Ry @ Rx
+    pose[:3, 3] = a[3:] * np.array([0.6, 0.3, 2.0]) + np.array([0, 0, 1.5])
+    pose = pose.astype(np.float32)
+    K = np.eye(3, dtype=np.float32)
+    K[0, 0] = K[1, 1] = 984.0
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    depth = 0.5 + 30.0 * uni(1) ** 2
+    u = (uni(2) * 1.3 - 0.15) * w
+    v = (uni(3) * 1.3 - 0.15) * h
+    cam = np.stack([(u - w / 2.0) / 984.0 * depth, (v - h / 2.0) / 984.0 * depth, depth, np.ones(npoints)], 1)
+    kind = rand_below(seed, 4, idx, 20)
+    cam[kind == 0, 2] *= -1          # behind the camera
+    cam[kind == 1, 2] += 40          # beyond the depth gate
+    world = (pose.astype(np.float64) @ cam.T).T[:, :3]
+    th = float(pose[2, 3])
+    return pose, K, world.astype(np.float32), th

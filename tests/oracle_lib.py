@@ -203,3 +203,31 @@ def search_by_projection(kp_xy, frame_desc, kp_idx, uv, point_desc, point_ids, r
                                    _p(uv, f32p), _p(point_desc), _p(point_ids, i32p), len(uv),
                                    C.c_float(radius), max_hamming, _p(out, i32p))
     return out[:len(kp_idx)]
+
+
+def invert4x4(m):
+    m = np.ascontiguousarray(m, np.float32)
+    out = np.zeros((4, 4), np.float32)
+    ok = lib().orc_invert4x4(_p(m), _p(out))
+    return out, bool(ok)
+
+
+def matmul4x4(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    out = np.zeros((4, 4), np.float32)
+    lib().orc_matmul4x4(_p(a), _p(b), _p(out))
+    return out
+
+
+def reproject(pose, K, xyz, th, W, H):
+    pose = np.ascontiguousarray(pose, np.float32)
+    K = np.ascontiguousarray(K, np.float32)
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    n = len(xyz)
+    uv = np.zeros((max(n, 1), 2), np.float32)
+    idx = np.zeros(max(n, 1), np.int32)
+    lib().orc_reproject.restype = C.c_int
+    r = lib().orc_reproject(_p(pose), _p(K), _p(xyz), n, C.c_float(th), C.c_float(W), C.c_float(H),
+                            _p(uv), _p(idx))
+    return uv[:r].copy(), idx[:r].copy()

@@ -225,3 +225,71 @@ def resize_linear_8u(src, fx, fy):
     r0, r1 = rows[y0], rows[y1]
     v = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
     return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def invert_lu_f32(m):
+    """Inverse of a square float32 matrix by Gaussian elimination with partial
+    pivoting on [A | I], every operation rounded to float32, the pivot's
+    reciprocal stored and used in the back-substitution (cv::invert, DECOMP_LU)."""
+    f = np.float32
+    n = len(m)
+    A = [[f(v) for v in row] for row in np.asarray(m, np.float32)]
+    B = [[f(1) if i == j else f(0) for j in range(n)] for i in range(n)]
+    for i in range(n):
+        k = max(range(i, n), key=lambda j: (abs(A[j][i]), -j))
+        if abs(A[k][i]) < f(np.finfo(np.float32).eps) * f(10):
+            return np.zeros((n, n), np.float32), False
+        A[i], A[k] = A[k], A[i]
+        B[i], B[k] = B[k], B[i]
+        d = f(-1) / A[i][i]
+        for j in range(i + 1, n):
+            alpha = A[j][i] * d
+            for c in range(i + 1, n):
+                A[j][c] = A[j][c] + alpha * A[i][c]
+            for c in range(n):
+                B[j][c] = B[j][c] + alpha * B[i][c]
+        A[i][i] = -d
+    for i in range(n - 1, -1, -1):
+        for j in range(n):
+            s = B[i][j]
+            for c in range(i + 1, n):
+                s = s - A[i][c] * B[c][j]
+            B[i][j] = s * A[i][i]
+    return np.array(B, np.float32), True
+
+
+def matmul_f32(a, b):
+    """Small-matrix product with float32 products summed left to right in float32."""
+    f = np.float32
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    out = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    for i in range(a.shape[0]):
+        for j in range(b.shape[1]):
+            acc = f(a[i, 0]) * f(b[0, j])
+            for k in range(1, a.shape[1]):
+                acc = f(acc + f(a[i, k]) * f(b[k, j]))
+            out[i, j] = acc
+    return out
+
+
+def reproject(pose, K, xyz, th, W, H):
+    """The loop of Init.cc:203-218 written out literally."""
+    f = np.float32
+    kf, _ = invert_lu_f32(pose)
+    K4 = np.eye(4, dtype=np.float32)
+    K4[:3, :3] = K
+    M = matmul_f32(K4, kf)
+    uv, idx = [], []
+    for i, (x, y, z) in enumerate(np.asarray(xyz, np.float32).reshape(-1, 3)):
+        if z < f(th) or abs(float(f(z - f(th)))) > 20:
+            continue
+        with np.errstate(all="ignore"):
+            pt = matmul_f32(M, np.array([[x], [y], [z], [1]], np.float32))[:, 0]
+            pt = pt * f(1.0 / float(pt[3]))
+            pt = pt * f(1.0 / float(pt[2]))
+        if pt[0] <= 0 or pt[0] >= f(W) or pt[1] <= 0 or pt[1] >= f(H):
+            continue
+        uv.append((pt[0], pt[1]))
+        idx.append(i)
+    return np.array(uv, np.float32).reshape(-1, 2), np.array(idx, np.int32)

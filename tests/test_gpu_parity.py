@@ -282,6 +282,55 @@ def test_search_by_projection_dense_cluster(fe_orb):
     assert (got >= 0).sum() >= 100
 
 
+@pytest.mark.parametrize("w,h,n,seed", [(1241, 376, 20000, 7), (640, 480, 3000, 8), (640, 480, 1, 9),
+                                        (640, 480, 257, 10)])
+def test_reproject_map_points(fe_orb, w, h, n, seed):
+    pose, K, xyz, th = synth.camera_scene(n, w, h, seed)
+    fe_orb.map_put_xyz(np.arange(n), xyz)
+    uv, idx = fe_orb.reproject(pose, K, th, w, h, n)
+    want_uv, want_idx = O.reproject(pose, K, xyz, th, w, h)
+    assert np.array_equal(idx, want_idx)
+    assert np.array_equal(uv.view(np.uint32), want_uv.view(np.uint32))
+    assert fe_orb.reproject(pose, K, th, w, h, n, download=False) == len(want_idx)
+    assert fe_orb.reproject(pose, K, th, w, h, 0) [1].size == 0
+
+
+def test_reproject_singular_pose_is_an_error(fe_orb):
+    from slam_amd.frontend import SlamfeError
+    with pytest.raises(SlamfeError):
+        fe_orb.reproject(np.ones((4, 4), np.float32), np.eye(3, dtype=np.float32), 0.0, 640, 480, 10)
+
+
+def test_reproject_then_search_on_device(fe_orb):
+    # Init.cc:203-259 end to end: reprojection feeds the search without a host round trip
+    w, h, n = 640, 480, 6000
+    img = synth.textured_canvas(w, h, 71)
+    f = fe_orb.extract_keypoints(img)
+    pose, K, xyz, th = synth.camera_scene(n, w, h, 12)
+    want_uv, want_idx = O.reproject(pose, K, xyz, th, w, h)
+    assert len(want_idx) > 1000
+    # descriptors: visible point j looks like the keypoint nearest to its projection (some perturbed)
+    xy = np.stack([f.keypoints["x"], f.keypoints["y"]], 1)
+    rng = np.random.default_rng(3)
+    desc = synth.random_descriptors(n, 13, 1)
+    for j, (p, i) in enumerate(zip(want_uv, want_idx)):
+        if j % 3:
+            k = int(np.argmin(((xy - p) ** 2).sum(1)))
+            d = f.descriptors[k].copy()
+            d[rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+            desc[i] = d
+    fe_orb.map_put(np.arange(n), desc)
+    fe_orb.map_put_xyz(np.arange(n), xyz)
+    kp_idx = rng.permutation(len(f))[:1500].astype(np.int32)
+    assert fe_orb.reproject(pose, K, th, w, h, n, download=False) == len(want_idx)
+    got = fe_orb.search_by_projection_visible(f, kp_idx)
+    want = O.search_by_projection(xy, f.descriptors, kp_idx, want_uv, desc[want_idx], want_idx)
+    assert np.array_equal(got, want)
+    assert (got >= 0).sum() > 100
+    # the host-round-trip form gives the same answer
+    assert np.array_equal(fe_orb.search_by_projection(f, kp_idx, want_uv, want_idx), want)
+
+
 def test_search_by_projection_no_points(fe_orb):
     img = synth.textured_canvas(200, 160, 52)
     f = fe_orb.extract_keypoints(img)

@@ -338,6 +338,62 @@ def _projection_case(nk=120, npts=300, seed=31):
     return xy, fd, inl, uv, pd, ids
 
 
+def test_invert4x4_known_answers_and_slow_definition():
+    eye = np.eye(4, dtype=np.float32)
+    inv, ok = O.invert4x4(eye)
+    assert ok and np.array_equal(inv, eye)
+    d = np.diag(np.array([2, 4, 0.5, 8], np.float32))
+    inv, ok = O.invert4x4(d)
+    assert ok and np.array_equal(inv, np.diag(np.array([0.5, 0.25, 2, 0.125], np.float32)))
+    perm = eye[[2, 0, 3, 1]]   # forces pivoting; the inverse of a permutation is its transpose
+    inv, ok = O.invert4x4(perm)
+    assert ok and np.array_equal(inv, perm.T)
+    sing = np.ones((4, 4), np.float32)
+    inv, ok = O.invert4x4(sing)   # cv::invert: false and an all-zero result
+    assert not ok and not inv.any()
+    rng = np.random.default_rng(11)
+    for _ in range(20):
+        m = rng.normal(size=(4, 4)).astype(np.float32)
+        got, ok = O.invert4x4(m)
+        want, ok2 = S.invert_lu_f32(m)
+        assert ok == ok2 and np.array_equal(got, want)
+        assert np.abs(got.astype(np.float64) @ m - np.eye(4)).max() < 1e-3
+        b = rng.normal(size=(4, 4)).astype(np.float32)
+        assert np.array_equal(O.matmul4x4(m, b), S.matmul_f32(m, b))
+
+
+@pytest.mark.parametrize("w,h,n,seed", [(1241, 376, 1500, 7), (640, 480, 800, 8)])
+def test_reproject_matches_literal_loop(w, h, n, seed):
+    pose, K, xyz, th = synth.camera_scene(n, w, h, seed)
+    uv, idx = O.reproject(pose, K, xyz, th, w, h)
+    uv2, idx2 = S.reproject(pose, K, xyz, th, w, h)
+    assert 0.2 * n < len(idx) < 0.9 * n
+    assert np.array_equal(idx, idx2) and np.array_equal(uv, uv2)
+    assert np.all(np.diff(idx) > 0)
+    assert (uv[:, 0] > 0).all() and (uv[:, 0] < w).all() and (uv[:, 1] > 0).all() and (uv[:, 1] < h).all()
+    # against the pinhole model in double: same pixels to float accuracy
+    cam = (np.linalg.inv(pose.astype(np.float64)) @ np.c_[xyz[idx].astype(np.float64), np.ones(len(idx))].T).T
+    ref = (K.astype(np.float64) @ (cam[:, :3] / cam[:, 2:3]).T).T[:, :2]
+    assert np.abs(ref - uv).max() < 0.05
+
+
+def test_reproject_gates():
+    pose = np.eye(4, dtype=np.float32)
+    K = np.array([[100, 0, 50], [0, 100, 40], [0, 0, 1]], np.float32)
+    xyz = np.array([[0, 0, 1],        # centre: (50, 40)
+                    [0, 0, -1],       # z < th
+                    [0, 0, 20.5],     # |z - th| > 20
+                    [0, 0, 20],       # |z - th| == 20 stays
+                    [-0.5, 0, 1],     # u == 0: out (strict)
+                    [0.5, 0, 1],      # u == W: out
+                    [0, -0.4, 1],     # v == 0: out
+                    [0.49, 0.39, 1]], np.float32)
+    uv, idx = O.reproject(pose, K, xyz, 0.0, 100, 80)
+    assert idx.tolist() == [0, 3, 7]
+    assert uv[0].tolist() == [50, 40] and uv[1].tolist() == [50, 40]
+    assert np.allclose(uv[2], [99, 79])
+
+
 def test_search_by_projection_matches_literal_loop():
     xy, fd, inl, uv, pd, ids = _projection_case()
     got = O.search_by_projection(xy, fd, inl, uv, pd, ids)
