@@ -4,6 +4,7 @@
 // usage: test_host_adapter frameA.raw frameB.raw width height
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "slamfe_host.hpp"
@@ -112,7 +113,56 @@ int main(int argc, char** argv)
             hits += got[i] >= 0;
         }
         REQUIRE(hits >= (int)rIds.size() / 2);
-        std::printf("host adapter ok: %d/%d keypoints, %d good matches, %d map hits\n", n1, n2, oracle_good, hits);
+
+        // the same search with the reprojection done by the library (Init.cc:203-218):
+        // map points placed on the rays of their pixels under an identity pose
+        const float f = 984.0f, K[9] = {f, 0, W / 2.0f, 0, f, H / 2.0f, 0, 0, 1};
+        const float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        std::vector<float> xyz;
+        for (size_t j = 0; j < rIds.size(); ++j) {
+            float z = 2.0f + (float)(j % 7);
+            xyz.push_back((uv[2 * j] - K[2]) / f * z);
+            xyz.push_back((uv[2 * j + 1] - K[5]) / f * z);
+            xyz.push_back(z);
+        }
+        fe.mapPutXyz(rIds, xyz);
+        std::vector<float> ruv, ouv(uv.size());
+        std::vector<int> ridx;
+        std::vector<int32_t> oidx(rIds.size());
+        int R = fe.reproject(pose, K, pose[11], (float)W, (float)H, (int)rIds.size(), ruv, ridx);
+        int oR = orc_reproject(pose, K, xyz.data(), (int)rIds.size(), pose[11], (float)W, (float)H, ouv.data(),
+                               oidx.data());
+        REQUIRE(R == oR && R > (int)rIds.size() / 2);
+        REQUIRE(std::memcmp(ruv.data(), ouv.data(), (size_t)R * 8) == 0);
+        REQUIRE(std::memcmp(ridx.data(), oidx.data(), (size_t)R * 4) == 0);
+        std::vector<int> got2 = fe.searchByProjectionVisible(h2, inl);
+        std::vector<uint8_t> vdesc;
+        for (int j = 0; j < R; ++j) vdesc.insert(vdesc.end(), pdesc.begin() + 32 * oidx[(size_t)j], pdesc.begin() + 32 * oidx[(size_t)j] + 32);
+        orc_search_by_projection(kxy.data(), d2.data(), inl.data(), (int)inl.size(), ouv.data(), vdesc.data(),
+                                 oidx.data(), R, 32.f, 128, want.data());
+        for (size_t i = 0; i < inl.size(); ++i) REQUIRE(got2[i] == want[i]);
+
+        // cv::resize(frame, frame, Size(), 0.99, 0.99) + extractKeyPoints (Init.cc:103, 113)
+        std::vector<uint8_t> bgr((size_t)W * H * 3), resized, oresized((size_t)W * H * 3);
+        for (size_t i = 0; i < (size_t)W * H; ++i) {
+            bgr[3 * i] = fa[i];
+            bgr[3 * i + 1] = fb[i];
+            bgr[3 * i + 2] = (uint8_t)((fa[i] + fb[i]) / 2);
+        }
+        int rw = 0, rh = 0, ow = 0, oh = 0;
+        std::vector<slamfe::KeyPoint> keypoints3;
+        slamfe::Mat8 descriptors3;
+        fe.resizeAndExtract({bgr.data(), W, H, W * 3, 3}, 0.99, 0.99, resized, rw, rh, keypoints3, descriptors3);
+        orc_scaled_size(W, H, 0.99, 0.99, &ow, &oh);
+        REQUIRE(rw == ow && rh == oh);
+        orc_resize_linear_8u(bgr.data(), W, H, W * 3, 3, 0.99, 0.99, oresized.data(), ow * 3);
+        REQUIRE(std::memcmp(resized.data(), oresized.data(), (size_t)ow * oh * 3) == 0);
+        int n3 = orc_extract(&p, oresized.data(), ow, oh, ow * 3, 3, ORC_TRIG_CONTRACT, k1.data(), d1.data(), cap);
+        REQUIRE((int)keypoints3.size() == n3 && n3 > 100);
+        REQUIRE(std::memcmp(keypoints3.data(), k1.data(), (size_t)n3 * sizeof(slamfe_keypoint)) == 0);
+        REQUIRE(std::memcmp(descriptors3.data.data(), d1.data(), (size_t)n3 * 32) == 0);
+        std::printf("host adapter ok: %d/%d keypoints, %d good matches, %d map hits, %d reprojected, %d keypoints after resize\n",
+                    n1, n2, oracle_good, hits, R, n3);
     } catch (const slamfe::Error& e) {
         std::fprintf(stderr, "slamfe::Error %d: %s\n", e.code, e.what());
         return 3;
