@@ -687,14 +687,38 @@ __global__ __launch_bounds__(256) void k_select_write(
 // ---------------------------------------------------------------------------
 // K5  orientation by intensity centroid (ICAngles inside cv::ORB).
 //
-// k_orient: one wavefront per keypoint sums the moments of the 749-pixel disc.
-// Each row of the disc (31 bytes starting at cx-15) is read as 9 aligned dwords;
-// a lane masks the bytes outside the disc and gets the row-sum S and the
-// position-weighted sum T of its 4 pixels from two v_dot4_u32_u8:
-//   m10 += u0 * S + T,  m01 += v * S      (u0 = x-offset of the dword's byte 0)
+// k_orient: a wavefront sums the moments of a keypoint's 749-pixel disc.
 // k_finish: one lane per keypoint turns the moments into the angle
 // (fastAtan2), its cos/sin for the descriptor, and the cv::KeyPoint record.
 // ---------------------------------------------------------------------------
+// Sum over the 64 lanes of a wavefront, result in every lane: butterflies inside
+// a row of 16 lanes through DPP (no LDS traffic), then the four row sums through
+// v_readlane.
+__device__ __forceinline__ int wave_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false); // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false); // row_mirror
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) +
+           __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// A wavefront walks keypoints idx = wave, wave + nwaves, ...  The disc's 31 rows
+// of 31 bytes (starting at cx-15) are cut into 8 dwords each, 248 (row, dword)
+// tasks = 4 per lane.  Which bytes of a task lie inside the disc, their
+// x-offsets u and the row offset v depend on the lane only, so they are turned
+// once per wave into byte weights for v_dot4_u32_u8:
+//   T += dot4(x, inside ? u + 32 : 0)   S += dot4(x, inside ? 1 : 0)
+//   V += dot4(x, inside ? v + 16 : 0)   m10 = T - 32 S,  m01 = V - 16 S
+// leaving three dot products per loaded dword for every keypoint.
 __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
                                                 int slot_base, int nslots,
                                                 const uint32_t* __restrict__ kp_key,
@@ -705,49 +729,68 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
     const int f = wg_frame();
     if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
-    const int idx = wg_item() * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    // wave-uniform values are made scalar explicitly so that the per-keypoint reads
+    // below (key, level, level geometry) become scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(wg_item() * 4 + (int)(threadIdx.x >> 6));
+    const int nwaves = (int)gridDim.y * 4;
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
-    if (idx >= n) return;
-    const uint32_t key = kp_key[(size_t)slot * max_kp + idx];
-    const int l = (int)kp_level[(size_t)slot * max_kp + idx];
-    if (l < 0 || l >= g.nlevels) return; // never true for entries written by k_select_write
-    const slamfe_dev_level L = g.lv[l];
-    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
-    if (cx < 19 || cy < 16 || cx >= L.w - 21 || cy >= L.h - 16) return; // patch must be inside
-    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
+    if (wave >= n) return;
     // half-widths of the disc rows |v| = 0..15, one nibble each
     const unsigned long long umax = 0x3689abcddeeeffffULL;
-    const int a0 = (cx - 15) & ~3; // aligned start of every row's 36-byte span
-    int m10 = 0, m01 = 0;
+    uint32_t wT[4], wV[4], wS[4];
+    int trow[4], tcol[4];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        int t = it * 64 + lane; // (row, dword) task, 31 x 9 = 279 of them
-        int row = t / 9, dw = t - row * 9;
-        if (row < 31) {
-            int v = row - 15;
-            int av = v < 0 ? -v : v;
-            int d = (int)((umax >> (4 * av)) & 15ULL);
-            int u0 = a0 + 4 * dw - cx;
-            int klo = max(-d - u0, 0), khi = min(d - u0, 3);
-            if (khi >= klo) {
-                uint32_t x = *reinterpret_cast<const uint32_t*>(img + (size_t)(cy + v) * L.pitch + a0 + 4 * dw);
-                uint32_t mask = (0xffffffffu >> (8 * (3 - khi))) & (0xffffffffu << (8 * klo));
-                x &= mask;
-                int S = (int)__builtin_amdgcn_udot4(x, 0x01010101u, 0u, false);
-                int T = (int)__builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
-                m10 += u0 * S + T;
-                m01 += v * S;
+    for (int it = 0; it < 4; ++it) {
+        const int t = it * 64 + lane, row = t >> 3, dw = t & 7;
+        const int v = row - 15, av = v < 0 ? -v : v;
+        const int d = row < 31 ? (int)((umax >> (4 * av)) & 15ULL) : -1;
+        uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * dw + k - 15;
+            if (u >= -d && u <= d) {
+                a |= (uint32_t)(u + 32) << (8 * k);
+                b |= (uint32_t)(v + 16) << (8 * k);
+                c |= 1u << (8 * k);
             }
         }
+        wT[it] = a;
+        wV[it] = b;
+        wS[it] = c;
+        trow[it] = row < 31 ? row : 0;
+        tcol[it] = 4 * dw;
     }
+    const uint8_t* frame = pyr + (size_t)f * g.frame_bytes;
+    const uint32_t* keys = kp_key + (size_t)slot * max_kp;
+    const uint32_t* levels = kp_level + (size_t)slot * max_kp;
+    uint32_t next_key = keys[wave], next_level = levels[wave];
+    for (int idx = wave; idx < n; idx += nwaves) { // uniform per wave
+        const uint32_t key = next_key;
+        const int l = (int)next_level;
+        if (idx + nwaves < n) { // fetched while this keypoint is processed
+            next_key = keys[idx + nwaves];
+            next_level = levels[idx + nwaves];
+        }
+        if (l < 0 || l >= g.nlevels) continue; // never true for entries written by k_select_write
+        const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
+        const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+        if (cx < 16 || cy < 16 || cx >= w - 17 || cy >= h - 16) continue; // reads must stay inside
+        const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 15) * pitch + (cx - 15);
+        uint32_t T = 0, V = 0, S = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
+        for (int it = 0; it < 4; ++it) {
+            uint32_t x = 0;
+            if (it < 3 || lane < 56) x = load_u32_unaligned(base + trow[it] * pitch + tcol[it]);
+            T = __builtin_amdgcn_udot4(x, wT[it], T, false);
+            V = __builtin_amdgcn_udot4(x, wV[it], V, false);
+            S = __builtin_amdgcn_udot4(x, wS[it], S, false);
+        }
+        const int m10 = wave_sum((int)T - 32 * (int)S);
+        const int m01 = wave_sum((int)V - 16 * (int)S);
+        if (lane == 0) kp_mom[(size_t)slot * max_kp + idx] = make_int2(m10, m01);
     }
-    if (lane == 0) kp_mom[(size_t)slot * max_kp + idx] = make_int2(m10, m01);
 }
 
 __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base, int nslots,
@@ -1432,7 +1475,12 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          int max_kp, int mode, int patch_size)
 {
     if (mode == SLAMFE_MODE_ORB) {
-        hipLaunchKernelGGL(k_orient, frame_grid((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, pyr,
+        // about four keypoints per wavefront when the level quotas are met exactly;
+        // the kernel loops, so any count up to max_kp is covered
+        int est = 0;
+        for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
+        if (est < 64 || est > max_kp) est = max_kp;
+        hipLaunchKernelGGL(k_orient, frame_grid((est + 15) / 16, nframes), dim3(256), 0, s, g, pyr,
                            slot_base, nslots, kp_key, kp_level, kp_count,
                            reinterpret_cast<int2*>(kp_mom), max_kp, nframes);
         LAUNCH_CHECK();
