@@ -840,12 +840,22 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
 
 // ---------------------------------------------------------------------------
 // K7  rBRIEF-256 (computeOrbDescriptors inside cv::ORB, reached from
-//     desc->compute, Init.cc:78).  One wavefront per keypoint; lane i evaluates
-//     tests i, 64+i, 128+i, 192+i, so each wave ballot is 8 descriptor bytes.
+//     desc->compute, Init.cc:78).  Lane i of a wavefront evaluates tests i,
+//     64+i, 128+i, 192+i, so each wave ballot is 8 descriptor bytes.
 // ---------------------------------------------------------------------------
 #define DP_ROWS 37 /* samples reach +-18 px (|pattern| <= 13 * sqrt 2 = 18.4) */
-#define DP_DW 10   /* 37 bytes from an aligned start: 40 bytes = 10 dwords */
+#define DP_DW 10   /* 37 bytes from column cx-18, read as 10 dwords */
 
+// A wavefront walks keypoints idx = wave, wave + nwaves, ...  For each one it
+// stages the 37-row neighbourhood (rows of 40 bytes starting at cx-18,
+// unaligned dword loads) in its own LDS slice and gathers the 512 samples from
+// there.  Per-lane constants (the lane's four tests as floats, its staging
+// tasks) are set up once per wave.  The rotation is evaluated on float pairs
+// (x, y) = P * (a, b) + Q * (-b, a): the same products and one sum per
+// coordinate as the scalar expressions x = px*a - py*b, y = px*b + py*a, so the
+// bits are identical.  Rounding to the nearest integer (ties to even, as
+// cvRound) is the addition of 1.5 * 2^23, which leaves the integer in the low
+// mantissa bits.
 __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8_t* __restrict__ blur,
                                                   int slot_base, int nslots,
                                                   const uint32_t* __restrict__ kp_key,
@@ -854,56 +864,95 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   const float2* __restrict__ kp_rot,
                                                   uint8_t* __restrict__ desc, int max_kp, int nframes)
 {
-    // each wavefront stages the 37-row neighbourhood of its keypoint in LDS with
-    // row-contiguous dword loads, then gathers its 512 samples from LDS
+    typedef float v2f __attribute__((ext_vector_type(2)));
     __shared__ uint32_t patch32[4][DP_ROWS * DP_DW];
     const int f = wg_frame();
     if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
     const int wv = threadIdx.x >> 6;
-    const int idx = wg_item() * 4 + wv;
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(wg_item() * 4 + wv);
+    const int nwaves = (int)gridDim.y * 4;
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
-    if (idx >= n) return;
-    const uint32_t key = kp_key[(size_t)slot * max_kp + idx];
-    const int l = (int)kp_level[(size_t)slot * max_kp + idx];
-    if (l < 0 || l >= g.nlevels) return; // never true for entries written by k_select_write
-    const slamfe_dev_level L = g.lv[l];
-    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
-    if (cx < 22 || cy < 19 || cx >= L.w - 22 || cy >= L.h - 19) return; // patch must be inside
-    const float2 rot = kp_rot[(size_t)slot * max_kp + idx];
-    const float a = rot.x, b = rot.y; // cos, sin of the keypoint angle
-    const uint8_t* img = blur + (size_t)f * g.frame_bytes + L.off;
-    const int ax = (cx - 18) & ~3; // aligned start column of the staged rows
-    uint32_t* my = patch32[wv];
-#pragma unroll
-    for (int it = 0; it < (DP_ROWS * DP_DW + 63) / 64; ++it) {
-        int t = it * 64 + lane;
-        int row = t / DP_DW, dw = t - row * DP_DW;
-        if (row < DP_ROWS)
-            my[t] = *reinterpret_cast<const uint32_t*>(img + (size_t)(cy - 18 + row) * L.pitch + ax + 4 * dw);
-    }
-    // only this wavefront reads what it wrote: LDS operations of one wave are
-    // ordered, the fence keeps the compiler from moving the reads up
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * (DP_DW * 4) + (cx - ax);
-    unsigned long long word[4];
+    if (wave >= n) return;
+    v2f P[4][2], Q[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int8_t* t = c_pattern + (j * 64 + lane) * 4;
-        float px0 = (float)t[0], py0 = (float)t[1], px1 = (float)t[2], py1 = (float)t[3];
-        float x0 = px0 * a - py0 * b, y0 = px0 * b + py0 * a;
-        float x1 = px1 * a - py1 * b, y1 = px1 * b + py1 * a;
-        int v0 = c[slamfe_round_f(y0) * (DP_DW * 4) + slamfe_round_f(x0)];
-        int v1 = c[slamfe_round_f(y1) * (DP_DW * 4) + slamfe_round_f(x1)];
-        word[j] = __ballot(v0 < v1);
+        P[j][0] = (v2f){(float)t[0], (float)t[0]};
+        Q[j][0] = (v2f){(float)t[1], (float)t[1]};
+        P[j][1] = (v2f){(float)t[2], (float)t[2]};
+        Q[j][1] = (v2f){(float)t[3], (float)t[3]};
     }
-    if (lane < 4) {
-        unsigned long long w = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
-        reinterpret_cast<unsigned long long*>(desc + ((size_t)slot * max_kp + idx) * 32)[lane] = w;
+    constexpr int NIT = (DP_ROWS * DP_DW + 63) / 64;
+    int trow[NIT], tcol[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int t = it * 64 + lane, row = t / DP_DW;
+        trow[it] = row < DP_ROWS ? row : 0;
+        tcol[it] = 4 * (t - row * DP_DW);
+    }
+    uint32_t* my = patch32[wv];
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * (DP_DW * 4) + 18;
+    const uint8_t* frame = blur + (size_t)f * g.frame_bytes;
+    const uint32_t* keys = kp_key + (size_t)slot * max_kp;
+    const uint32_t* levels = kp_level + (size_t)slot * max_kp;
+    const float2* rots = kp_rot + (size_t)slot * max_kp;
+    uint32_t next_key = keys[wave], next_level = levels[wave];
+    float2 next_rot = rots[wave];
+    for (int idx = wave; idx < n; idx += nwaves) { // uniform per wave
+        const uint32_t key = next_key;
+        const int l = (int)next_level;
+        const float2 rot = next_rot; // cos, sin of the keypoint angle
+        if (idx + nwaves < n) {      // fetched while this keypoint is processed
+            next_key = keys[idx + nwaves];
+            next_level = levels[idx + nwaves];
+            next_rot = rots[idx + nwaves];
+        }
+        if (l < 0 || l >= g.nlevels) continue; // never true for entries written by k_select_write
+        const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
+        const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+        if (cx < 18 || cy < 18 || cx >= w - 22 || cy >= h - 18) continue; // reads must stay inside
+        const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 18) * pitch + (cx - 18);
+        uint32_t r[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            r[it] = 0;
+            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_DW)
+                r[it] = load_u32_unaligned(base + trow[it] * pitch + tcol[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_DW) my[it * 64 + lane] = r[it];
+        // only this wavefront reads what it wrote: LDS operations of one wave are
+        // ordered, the fences keep the compiler from moving accesses across
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
+        const v2f magic = {12582912.f, 12582912.f};
+        unsigned long long word[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v2f pt = P[j][e] * AB + Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
+                pt = pt + magic;
+                const int ix = (short)__float_as_int(pt.x), iy = (short)__float_as_int(pt.y);
+                v[e] = c[iy * (DP_DW * 4) + ix];
+            }
+            word[j] = __ballot(v[0] < v[1]);
+        }
+        if (lane < 4) {
+            unsigned long long o = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+            reinterpret_cast<unsigned long long*>(desc + ((size_t)slot * max_kp + idx) * 32)[lane] = o;
+        }
+        // the next keypoint's staging must not overtake these LDS reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -1477,10 +1526,10 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
     if (mode == SLAMFE_MODE_ORB) {
         // about four keypoints per wavefront when the level quotas are met exactly;
         // the kernel loops, so any count up to max_kp is covered
-        int est = 0;
+        long long est = 0;
         for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
         if (est < 64 || est > max_kp) est = max_kp;
-        hipLaunchKernelGGL(k_orient, frame_grid((est + 15) / 16, nframes), dim3(256), 0, s, g, pyr,
+        hipLaunchKernelGGL(k_orient, frame_grid((int)((est + 15) / 16), nframes), dim3(256), 0, s, g, pyr,
                            slot_base, nslots, kp_key, kp_level, kp_count,
                            reinterpret_cast<int2*>(kp_mom), max_kp, nframes);
         LAUNCH_CHECK();
@@ -1498,7 +1547,12 @@ int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes,
                            const uint32_t* kp_level, const int32_t* kp_count,
                            const float* kp_rot, uint8_t* desc, int max_kp)
 {
-    hipLaunchKernelGGL(k_describe, frame_grid((max_kp + 3) / 4, nframes), dim3(256), 0, s, g, blur,
+    // about four keypoints per wavefront when the level quotas are met exactly
+    // (cv::ORB), a wavefront per four slots of capacity otherwise; the kernel loops
+    long long est = 0;
+    for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
+    if (est < 64 || est > max_kp) est = max_kp;
+    hipLaunchKernelGGL(k_describe, frame_grid((int)((est + 15) / 16), nframes), dim3(256), 0, s, g, blur,
                        slot_base, nslots, kp_key, kp_level, kp_count,
                        reinterpret_cast<const float2*>(kp_rot), desc, max_kp, nframes);
     LAUNCH_CHECK();
