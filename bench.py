@@ -171,10 +171,14 @@ def main():
             first = int(h[0])
             # frame i is matched against frame i-1; frame 0 against the last frame
             # of the previous step (on the very first step: against itself)
-            prev_last = state["last"] if state["last"] is not None else first
-            f.match_resident_batch(prev_last, first, 1, mo.data_ptr())
-            if B > 1:
-                f.match_resident_batch(first, first + 1, B - 1, mo[1:].data_ptr())
+            # (handles are consecutive, so from the second step on the previous
+            # step's last frame is handle first - 1 and all B pairs go in one call)
+            if state["last"] is not None and state["last"] == first - 1:
+                f.match_resident_batch(first - 1, first, B, mo.data_ptr())
+            else:
+                f.match_resident_batch(first, first, 1, mo.data_ptr())
+                if B > 1:
+                    f.match_resident_batch(first, first + 1, B - 1, mo[1:].data_ptr())
             state["last"] = first + B - 1
             hd = hd if hd is not None else h
         return hd
