@@ -40,6 +40,7 @@ from slam_amd.frontend import FrontEnd  # noqa: E402
 W, H, NFEAT, THR = 640, 480, 2000, 20
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TOPS = 41.0  # measured: tools/ubench_valu.hip, v_xor + accumulating v_bcnt
+MFMA_I8_PEAK_TOPS = 2048 * 1024 * 2.4e9 / 1e12  # dense int8 MFMA peak, 5033 TOP/s
 
 STAGES = {"pyramid": 1, "fast_blur": 2, "select": 3, "orient": 4, "describe": 6, "match": 7}
 
@@ -237,13 +238,16 @@ def main():
     # Hamming comparisons/s of the match kernel inside the frame pipeline
     cmps = float((all_counts[:-1] * all_counts[1:]).sum())
     gc = cmps / (stage_ms["match"] * 1e-3) / 1e9
-    # integer-VALU roofline of the match kernel: 16 lane-ops (8 xor + 8 popcount-
-    # accumulate) per 256-bit comparison against the measured issue ceiling of
-    # tools/ubench_valu.hip (41.0 T lane-ops/s on MI355X)
+    # The match kernel runs on the matrix cores: one 256-bit comparison = 256
+    # int8 multiply-accumulates = 512 operations of v_mfma_i32_32x32x32_i8, whose
+    # dense peak is 2048 op/clk/SIMD x 1024 SIMDs x 2.4 GHz.  (The integer-VALU
+    # formulation, 16 lane-ops per comparison, tops out at 41.0 T lane-ops/s =
+    # 2.56 T cmp/s: measured by tools/ubench_valu.hip.)
     hamming = {"frame_pairs_gcmps": round(gc, 2),
-               "valu_roofline": {"lane_ops_per_cmp": 16, "achieved_Tops": round(gc * 16 / 1e3, 2),
-                                 "peak_Tops": VALU_PEAK_TOPS,
-                                 "frac": round(gc * 16 / 1e3 / VALU_PEAK_TOPS, 4)}}
+               "mfma_roofline": {"bound": "mfma", "ops_per_cmp": 512,
+                                 "achieved": round(gc * 512 / 1e3, 1), "peak": MFMA_I8_PEAK_TOPS,
+                                 "unit": "TOP/s", "frac": round(gc * 512 / 1e3 / MFMA_I8_PEAK_TOPS, 4)},
+               "valu_formulation_ceiling_gcmps": round(VALU_PEAK_TOPS * 1e3 / 16, 1)}
 
     # relocalisation: 2000 queries against a 1M-row map sharded over the ranks
     if not args.no_reloc:
@@ -285,7 +289,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rel = float(t.item())
         hamming["reloc_2000x1M_gcmps"] = round(NQ * NT * R / rel / 1e9, 2)
-        hamming["reloc_valu_frac"] = round(NQ * NT * R / rel / 1e12 * 16 / (VALU_PEAK_TOPS * world), 4)
+        hamming["reloc_mfma_frac"] = round(NQ * NT * R / rel / 1e12 * 512 / (MFMA_I8_PEAK_TOPS * world), 4)
         hamming["reloc_ms_per_query_set"] = round(rel / R * 1e3, 4)
         hamming["reloc_scaling"] = "strong (map rows split over ranks, RCCL all-gather of top-2 keys)"
 

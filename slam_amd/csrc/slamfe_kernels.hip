@@ -1265,6 +1265,206 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
     }
 }
 
+// ---------------------------------------------------------------------------
+// K8m  the same brute-force Hamming k=2 on the matrix cores.
+//
+// With train bits a in {0, 1} and query bits mapped to b' = 1 - 2b in {+1, -1},
+//   sum_k a_k * b'_k = popcount(a) - 2 a.b = hamming(a, b) - popcount(b),
+// so one v_mfma_i32_32x32x32_i8 chain over the 256 bit positions (8 MFMAs) gives
+// the exact distances of 32 train rows x 32 queries, minus a per-query constant
+// that does not change the order.  In the result tile the query is the lane
+// (column) and the 16 registers are train rows, so the running top-2 of a query
+// stays in its lane: key = (dot + 256) << 22 | row-in-tile, one v_lshl_add per
+// distance, then v_min / v_med3 as in the VALU kernel.  Per comparison that is 3
+// VALU operations instead of 19; the 8 MFMAs of a tile take 256 cycles per SIMD.
+//
+// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to +-1 bytes in
+// 64 VGPRs per lane) x one chunk of train rows.  Train rows are read packed
+// (32 bytes), expanded to 0/1 bytes into LDS (one dword -> 32 bytes per thread
+// and tile, rows padded to 272 bytes so that the 16-byte fragment reads are
+// conflict-free), double-buffered.  Row indices inside the keys are relative to
+// the current tile (older entries are moved down by 32 per tile: 2 operations
+// per tile instead of re-basing 16 constants) and made absolute at the end.
+// ---------------------------------------------------------------------------
+#define MM_TILE 32
+#define MM_SUB 2 /* tiles per LDS stage (one workgroup barrier per stage) */
+#define MM_ROW 272
+#define MM_BIAS 8192u
+#define MM_SHIFT 22
+typedef int mm_v4i __attribute__((ext_vector_type(4)));
+typedef int mm_v16i __attribute__((ext_vector_type(16)));
+
+// bits pos .. pos+3 of x -> four bytes of 0 / 1 (bit i in byte i)
+__device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x, int pos)
+{
+    return (((x >> pos) & 0xFu) * 0x00204081u) & 0x01010101u;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_match_mfma(const uint32_t* __restrict__ query, int nq_imm,
+                                                    const int32_t* __restrict__ nq_dev,
+                                                    const uint32_t* __restrict__ train, int nt_imm,
+                                                    const int32_t* __restrict__ nt_dev,
+                                                    uint32_t* __restrict__ part, slamfe_pair_slots ps,
+                                                    slamfe_match_geo mg)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sA[2][MM_SUB][MM_TILE * MM_ROW];
+    const int pair = (int)(blockIdx.x % (unsigned)mg.npairs);
+    const int local = (int)(blockIdx.x / (unsigned)mg.npairs);
+    if (ps.nslots) {
+        int sq = (ps.q_base + pair) % ps.nslots, st = (ps.t_base + pair) % ps.nslots;
+        query += (size_t)sq * mg.cap * 8;
+        train += (size_t)st * mg.cap * 8;
+        nq_dev += sq;
+        nt_dev += st;
+        part += (size_t)pair * mg.nchunks * mg.cap * 2;
+    }
+    const int nq = nq_dev ? min(*nq_dev, mg.cap) : nq_imm;
+    const int nt = nt_dev ? min(*nt_dev, mg.cap) : nt_imm;
+    const int real_q = (nq + 255) / 256;
+    const int real_c = max(1, (nt + mg.chunk_rows - 1) / mg.chunk_rows);
+    if (local >= real_q * real_c) return;
+    const int qb256 = local / real_c, chunk = local - qb256 * real_c;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int j0 = chunk * mg.chunk_rows;
+    const int j1 = min(nt, j0 + mg.chunk_rows);
+    const int qfirst = qb256 * 256 + wv * 64 + r; // + 32 for the second block
+
+    if (j0 >= j1) { // an empty train set: every query of the workgroup gets "none"
+        for (int blk = 0; blk < 2; ++blk) {
+            int qi = qfirst + 32 * blk;
+            if (h == 0 && qi < nq)
+                reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
+                    make_uint2(SLAMFE_MKEY_NONE, SLAMFE_MKEY_NONE);
+        }
+        return;
+    }
+
+    // query fragments: lane (r, h) holds bits 16h .. 16h+15 of every dword of its
+    // query row as +-1 bytes
+    mm_v4i B[2][8];
+    int pq[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int qi = min(qfirst + 32 * blk, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t qw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        int pc = 0;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            pc += __popc(qw[kb]);
+            const uint32_t half = (qw[kb] >> (16 * h)) & 0xffffu;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint32_t t = bits4_to_bytes(half, 4 * n);
+                B[blk][kb][n] = (int)(((t << 8) - t) | 0x01010101u); // bit 1 -> 0xff (-1), bit 0 -> 0x01
+            }
+        }
+        pq[blk] = pc;
+    }
+
+    // a stage = MM_SUB tiles; the thread's piece of tile u of a stage: dword
+    // (tid & 7) of row (tid >> 3)
+    auto load_bits = [&](int st, int u) -> uint32_t {
+        const int row = j0 + (st * MM_SUB + u) * MM_TILE + (tid >> 3);
+        return row < j1 ? train[(size_t)row * 8 + (tid & 7)] : 0u;
+    };
+    auto store_tile = [&](int buf, int u, uint32_t bits) {
+        uint4 a, b;
+        a.x = bits4_to_bytes(bits, 0);  a.y = bits4_to_bytes(bits, 4);
+        a.z = bits4_to_bytes(bits, 8);  a.w = bits4_to_bytes(bits, 12);
+        b.x = bits4_to_bytes(bits, 16); b.y = bits4_to_bytes(bits, 20);
+        b.z = bits4_to_bytes(bits, 24); b.w = bits4_to_bytes(bits, 28);
+        uint4* d = reinterpret_cast<uint4*>(&sA[buf][u][(tid >> 3) * MM_ROW + (tid & 7) * 32]);
+        d[0] = a;
+        d[1] = b;
+    };
+    const int ntiles = (j1 - j0 + MM_TILE - 1) / MM_TILE;
+    const int nstages = (ntiles + MM_SUB - 1) / MM_SUB;
+#pragma unroll
+    for (int u = 0; u < MM_SUB; ++u) store_tile(0, u, load_bits(0, u));
+    __syncthreads();
+
+    // result register j of lane half h is train row (j & 3) + 8 (j >> 2) + 4 h of the tile
+    uint32_t cj[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cj[j] = (256u << MM_SHIFT) + MM_BIAS + (uint32_t)((j & 3) + 8 * (j >> 2) + 4 * h);
+    uint32_t b1[2] = {0xffffffffu, 0xffffffffu}, b2[2] = {0xffffffffu, 0xffffffffu};
+
+    for (int st = 0; st < nstages; ++st) {
+        uint32_t nbits[MM_SUB];
+#pragma unroll
+        for (int u = 0; u < MM_SUB; ++u) nbits[u] = st + 1 < nstages ? load_bits(st + 1, u) : 0u;
+#pragma unroll
+        for (int u = 0; u < MM_SUB; ++u) {
+            const int t = st * MM_SUB + u;
+            if (t >= ntiles) break; // uniform
+            const uint8_t* base = &sA[st & 1][u][r * MM_ROW + h * 16];
+            mm_v16i acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const mm_v4i a = *reinterpret_cast<const mm_v4i*>(base + kb * 32);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[0][kb], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[1][kb], acc1, 0, 0, 0);
+            }
+            // entries of earlier tiles move down by one tile
+            b1[0] -= MM_TILE; b2[0] -= MM_TILE; b1[1] -= MM_TILE; b2[1] -= MM_TILE;
+            const int rows = j1 - (j0 + t * MM_TILE); // valid rows of this tile (>= 32: all)
+            if (rows >= MM_TILE) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    uint32_t k0 = ((uint32_t)acc0[j] << MM_SHIFT) + cj[j];
+                    uint32_t k1 = ((uint32_t)acc1[j] << MM_SHIFT) + cj[j];
+                    uint32_t n0, n1;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
+                    b1[0] = min(k0, b1[0]); b2[0] = n0;
+                    b1[1] = min(k1, b1[1]); b2[1] = n1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool ok = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
+                    uint32_t k0 = ok ? ((uint32_t)acc0[j] << MM_SHIFT) + cj[j] : 0xffffffffu;
+                    uint32_t k1 = ok ? ((uint32_t)acc1[j] << MM_SHIFT) + cj[j] : 0xffffffffu;
+                    uint32_t n0, n1;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
+                    b1[0] = min(k0, b1[0]); b2[0] = n0;
+                    b1[1] = min(k1, b1[1]); b2[1] = n1;
+                }
+            }
+        }
+        if (st + 1 < nstages) {
+#pragma unroll
+            for (int u = 0; u < MM_SUB; ++u) store_tile((st + 1) & 1, u, nbits[u]);
+        }
+        __syncthreads();
+    }
+
+    // the two lane halves hold disjoint train rows of the same query: merge, then
+    // make distance and row absolute
+    const uint32_t last = (uint32_t)(ntiles - 1) * MM_TILE;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)b1[blk], 32), o2 = (uint32_t)__shfl_xor((int)b2[blk], 32);
+        const uint32_t m1 = min(b1[blk], o1);
+        const uint32_t m2 = min(max(b1[blk], o1), min(b2[blk], o2));
+        const int qi = qfirst + 32 * blk;
+        if (h == 0 && qi < nq) {
+            auto conv = [&](uint32_t k) -> uint32_t {
+                if (k >= 0xC0000000u) return SLAMFE_MKEY_NONE;
+                const uint32_t d = (k >> MM_SHIFT) - 256u + (uint32_t)pq[blk];
+                const uint32_t row = (k & ((1u << MM_SHIFT) - 1u)) - MM_BIAS + last + (uint32_t)j0;
+                return (d << SLAMFE_MKEY_SHIFT) | row;
+            };
+            reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
+                make_uint2(conv(m1), conv(m2));
+        }
+    }
+}
+
 __device__ __forceinline__ void top2_push(uint32_t k, uint32_t& b1, uint32_t& b2)
 {
     uint32_t mx = max(k, b1);
@@ -1722,21 +1922,31 @@ int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes,
 
 int slamfe_match_plan(int nq_max, int nt_max, int npairs, int* qpt, int* chunk_rows, int* nchunks)
 {
-    // Measured on MI355X (64 frame pairs of 2024 x 2024 rows, and 2000 x 1M rows):
-    // one query row per lane with 256- or 512-row chunks beats 2 or 4 rows per
-    // lane by 7-13 %: 54 VGPRs keep 9 waves per SIMD and the many small
-    // workgroups (thousands) even out over the 256 CUs.  Chunk sizes that are
-    // not a power of two ran up to 20 % slower, so only 128, 256 and 512 are used.
     if (npairs < 1) npairs = 1;
     long long qblocks = (nq_max + 255) / 256;
     if (qblocks < 1) qblocks = 1;
     const long long have = qblocks * npairs;
-    int rows = 256;
-    if (have * ((nt_max + 255) / 256) < 1024) rows = 128;       // small jobs: more workgroups
-    else if (have * ((nt_max + 511) / 512) >= 8192) rows = 512; // large train sets: fewer partials
+    int rows, q;
+    if (nq_max >= 128) {
+        // matrix-core kernel: a workgroup expands its 256 queries once (about the
+        // cost of three tiles), so chunks are long: 2048 rows for large train sets,
+        // 1024 for frame pairs (measured best on MI355X), less only when that
+        // would leave fewer than ~512 workgroups (a single frame pair)
+        q = 64;
+        rows = nt_max > 8192 ? 2048 : 1024;
+        while (rows > 256 && have * ((nt_max + rows - 1) / rows) < 512) rows >>= 1;
+    } else {
+        // few queries: the VALU kernel, one query row per lane.  Measured on MI355X:
+        // 256- or 512-row chunks beat 2 or 4 rows per lane by 7-13 %, and chunk
+        // sizes that are not a power of two ran up to 20 % slower.
+        q = 1;
+        rows = 256;
+        if (have * ((nt_max + 255) / 256) < 1024) rows = 128;
+        else if (have * ((nt_max + 511) / 512) >= 8192) rows = 512;
+    }
     int nc = (nt_max + rows - 1) / rows;
     if (nc < 1) nc = 1;
-    *qpt = 1;
+    *qpt = q;
     *chunk_rows = rows;
     *nchunks = nc;
     return 0;
@@ -1759,12 +1969,16 @@ int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int
     mg.npairs = npairs;
     mg.part_sq = wide ? nchunks : 1;
     mg.part_sc = wide ? 1 : cap;
-    int qblocks = (nq_grid + 256 * qpt - 1) / (256 * qpt);
+    int qblocks = (nq_grid + 255) / 256; // both kernels: 256 queries per workgroup
     dim3 grid((unsigned)qblocks * (unsigned)nchunks * (unsigned)npairs);
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(d_query);
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(d_train);
-    if (qpt != 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
+    if (qpt == 64)
+        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
+    else if (qpt == 1)
+        hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
+    else
+        return (int)hipErrorInvalidValue;
     LAUNCH_CHECK();
     if (wide)
         hipLaunchKernelGGL(k_match_merge<64>, dim3((nq_grid + 3) / 4, npairs), dim3(256), 0, s, part, nq,
