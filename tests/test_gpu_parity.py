@@ -187,7 +187,11 @@ def test_frame_handle_expires(fe_orb):
 
 # ------------------------------------------------------------------ matching
 @pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (1, 2), (257, 63), (64, 1000), (5, 0),
-                                   (3001, 2999), (100, 20000)])
+                                   (3001, 2999), (100, 20000),
+                                   # 128 queries and more take the matrix-core kernel: empty and
+                                   # one-row train sets, ragged tiles (rows % 32), chunk borders
+                                   (300, 0), (129, 1), (128, 2), (256, 33), (255, 1025), (513, 2049),
+                                   (130, 40000)])
 def test_match_knn2(fe_orb, nq, nt):
     q, t = synth.descriptor_sets(nq, max(nt, 1), seed=3 + nq, dup_percent=3)
     t = t[:nt]
@@ -197,6 +201,22 @@ def test_match_knn2(fe_orb, nq, nt):
         assert np.array_equal(got[name], want[name]), name
     if nt >= 1000:
         assert (got["d0"] == got["d1"]).sum() > 0  # ties were exercised
+
+
+def test_match_extreme_descriptors(fe_orb):
+    # all-zero, all-one and complementary rows: distances 0 and 256, every tie broken by index
+    q = np.zeros((200, 32), np.uint8)
+    q[1::2] = 0xFF
+    t = np.zeros((100, 32), np.uint8)
+    t[50:] = 0xFF
+    t[10, 0] = 1
+    got = fe_orb.knn_match(q, t)
+    want = O.match_knn2(q, t)
+    for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+        assert np.array_equal(got[name], want[name]), name
+    assert got["d0"].min() == 0 and got["idx0"][0] == 0 and got["idx1"][0] == 1
+    far = fe_orb.knn_match(q[:150], t[50:52] ^ 0)   # even queries are 256 away from both rows
+    assert far["d0"][0] == 256 and far["d1"][0] == 256 and far["idx0"][0] == 0
 
 
 def test_match_empty_query(fe_orb):
