@@ -42,10 +42,6 @@ struct slamfe_ctx {
     slamfe_params p;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // level 0 of a batch goes through FAST + blur on a second stream while the
-    // main stream still builds the rest of the pyramid
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_level0_ready = nullptr, ev_level0_done = nullptr;
     std::string err;
 
     // geometry of the frame size in use
@@ -310,22 +306,9 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     if (d_imgs)
         KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
                                      g.frame_bytes, g.lv[0].pitch));
-    const int split = g.nlevels > 1 ? g.lv[1].tile_base : g.total_tiles;
-    if (g.nlevels > 1 && c->aux_stream) {
-        HIPCHK(c, hipEventRecord(c->ev_level0_ready, s));
-        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_level0_ready, 0));
-        KCHK(c, slamfe_launch_fast_blur(c->aux_stream, g, n, c->pyr, c->blur, c->p.fast_threshold,
-                                        c->p.edge_threshold, c->cand, c->cand_cnt, 0, split));
-        HIPCHK(c, hipEventRecord(c->ev_level0_done, c->aux_stream));
-        KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
-        KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
-                                        c->p.edge_threshold, c->cand, c->cand_cnt, split, g.total_tiles));
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_level0_done, 0));
-    } else {
-        KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
-        KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
-                                        c->p.edge_threshold, c->cand, c->cand_cnt, 0, g.total_tiles));
-    }
+    KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
+    KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
+                                    c->p.edge_threshold, c->cand, c->cand_cnt));
     KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->band_hist, c->band_off, c->level_kept,
                                  c->level_cutoff, slot_base, c->nslots, c->kp_key, c->kp_level,
                                  c->kp_count, c->max_kp, c->sort_lds));
@@ -445,9 +428,6 @@ void slamfe_destroy(slamfe_ctx* c)
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
-    if (c->ev_level0_ready) (void)hipEventDestroy(c->ev_level0_ready);
-    if (c->ev_level0_done) (void)hipEventDestroy(c->ev_level0_done);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -495,9 +475,6 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_level0_ready, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_level0_done, hipEventDisableTiming));
     slamfe_dev_geom gmax;
     std::vector<uint32_t> tmax;
     build_geometry(p, p.max_width, p.max_height, &gmax, &tmax);
@@ -1089,7 +1066,7 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
             break;
         case SLAMFE_STAGE_FAST:
             KCHK(c, slamfe_launch_fast_blur(s, g, nframes, c->pyr, c->blur, c->p.fast_threshold,
-                                            c->p.edge_threshold, c->cand, c->cand_cnt, 0, g.total_tiles));
+                                            c->p.edge_threshold, c->cand, c->cand_cnt));
             break;
         case SLAMFE_STAGE_SELECT:
             KCHK(c, slamfe_launch_select(s, g, nframes, c->cand, c->cand_cnt, c->band_hist, c->band_off,

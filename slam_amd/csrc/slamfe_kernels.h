@@ -18,8 +18,7 @@ int slamfe_launch_ingest_scaled(hipStream_t s, const uint8_t* d_in, int stride, 
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
                           const uint32_t* taps);
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
-                            int tile_begin, int tile_end);
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt);
 int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,
                          const uint32_t* cand_cnt, uint32_t* band_hist, uint32_t* band_off,
                          uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,

@@ -308,7 +308,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
 __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
                                                    uint8_t* __restrict__ blur, int nframes, int thr,
                                                    int edge, uint32_t* __restrict__ cand,
-                                                   uint32_t* __restrict__ cand_cnt, int tile_begin)
+                                                   uint32_t* __restrict__ cand_cnt)
 {
     __shared__ uint32_t tile32[FL_H * FL_WD];
     __shared__ uint32_t sc32[(FS_N + 3) / 4];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
     uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
 
-    const int t = wg_item() + tile_begin, f = wg_frame(), tid = threadIdx.x;
+    const int t = wg_item(), f = wg_frame(), tid = threadIdx.x;
     if (f >= nframes) return;
     const int l = find_level_by_tile(g, t);
     const slamfe_dev_level L = g.lv[l];
@@ -1848,14 +1848,11 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
     return 0;
 }
 
-// Tiles [tile_begin, tile_end) of every frame (tiles are numbered level by level).
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
-                            int tile_begin, int tile_end)
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt)
 {
-    if (tile_end <= tile_begin) return 0;
-    hipLaunchKernelGGL(k_fast_blur, frame_grid(tile_end - tile_begin, nframes), dim3(256), 0, s, g, pyr,
-                       blur, nframes, thr, edge, cand, cand_cnt, tile_begin);
+    hipLaunchKernelGGL(k_fast_blur, frame_grid(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur,
+                       nframes, thr, edge, cand, cand_cnt);
     LAUNCH_CHECK();
     return 0;
 }
