@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="independent frame streams per GPU, each with its own context and HIP stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-reloc", action="store_true", help="skip the 1M-row matching leg")
