@@ -289,6 +289,25 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rel = float(t.item())
         hamming["reloc_2000x1M_gcmps"] = round(NQ * NT * R / rel / 1e9, 2)
+        if world == 1:
+            # the same job on the vector-ALU popcount kernel (v_xor + v_bcnt), against
+            # the measured integer-VALU ceiling: 16 lane-ops per comparison
+            with FrontEnd(mode=abi.MODE_ORB, nfeatures=NFEAT, max_width=W, max_height=H, max_batch=1,
+                          device_id=local_rank, stream=stream.cuda_stream, map_capacity=0,
+                          match_kernel=abi.MATCH_POPCOUNT) as fp:
+                with torch.cuda.stream(stream):
+                    for _ in range(3):
+                        fp.match_shard_keys(dq.data_ptr(), NQ, shard.data_ptr(), hi - lo, lo, keys.data_ptr())
+                    torch.cuda.synchronize(dev)
+                    p0 = time.perf_counter()
+                    for _ in range(10):
+                        fp.match_shard_keys(dq.data_ptr(), NQ, shard.data_ptr(), hi - lo, lo, keys.data_ptr())
+                    torch.cuda.synchronize(dev)
+                    pc = NQ * NT * 10 / (time.perf_counter() - p0) / 1e9
+            hamming["reloc_popcount_kernel_gcmps"] = round(pc, 2)
+            hamming["popcount_kernel_valu_roofline"] = {
+                "bound": "integer VALU", "lane_ops_per_cmp": 16, "achieved_Tops": round(pc * 16 / 1e3, 2),
+                "peak_Tops": VALU_PEAK_TOPS, "frac": round(pc * 16 / 1e3 / VALU_PEAK_TOPS, 4)}
         hamming["reloc_mfma_frac"] = round(NQ * NT * R / rel / 1e12 * 512 / (MFMA_I8_PEAK_TOPS * world), 4)
         hamming["reloc_ms_per_query_set"] = round(rel / R * 1e3, 4)
         hamming["reloc_scaling"] = "strong (map rows split over ranks, RCCL all-gather of top-2 keys)"

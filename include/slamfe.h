@@ -53,6 +53,14 @@ extern "C" {
 #define SLAMFE_MODE_ORB 0
 #define SLAMFE_MODE_PROVIDED 1
 
+/* The two brute-force Hamming kernels behind knnMatch (Init.cc:131); results are
+ * identical.  POPCOUNT: v_xor / v_bcnt on the vector ALU.  MATRIX: the bit
+ * vectors expanded to int8 and multiplied on the matrix cores (about twice as
+ * fast from 128 queries up).  AUTO: MATRIX from 128 queries up, else POPCOUNT. */
+#define SLAMFE_MATCH_AUTO 0
+#define SLAMFE_MATCH_POPCOUNT 1
+#define SLAMFE_MATCH_MATRIX 2
+
 /* Layout-identical to cv::KeyPoint (28 bytes).  Consumers in the reference
  * read only pt (Init.cc:150-151, 241, 280-283; optimizer.cc:97-98). */
 typedef struct slamfe_keypoint {
@@ -93,6 +101,8 @@ typedef struct slamfe_params {
     int32_t frame_slots;     /* device-resident frame results kept (ring) */
     int32_t map_capacity;    /* rows of the device-resident map descriptor table */
     void* stream;            /* hipStream_t to run on, or NULL to create one */
+    int32_t match_kernel;    /* SLAMFE_MATCH_*: which brute-force kernel knnMatch (Init.cc:131) uses */
+    int32_t reserved0;       /* 0 */
 } slamfe_params;
 
 typedef struct slamfe_ctx slamfe_ctx;

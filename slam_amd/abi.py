@@ -14,6 +14,7 @@ SLAMFE_E_HANDLE = -5
 
 MODE_ORB = 0
 MODE_PROVIDED = 1
+MATCH_AUTO, MATCH_POPCOUNT, MATCH_MATRIX = 0, 1, 2
 
 # cv::KeyPoint layout (28 bytes)
 KEYPOINT_DTYPE = np.dtype(
@@ -46,6 +47,8 @@ class Params(C.Structure):
         ("frame_slots", C.c_int32),
         ("map_capacity", C.c_int32),
         ("stream", C.c_void_p),
+        ("match_kernel", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

@@ -407,6 +407,8 @@ int slamfe_default_params(slamfe_params* p)
     p->frame_slots = 0;   // chosen from max_batch
     p->map_capacity = 1 << 16;
     p->stream = nullptr;
+    p->match_kernel = SLAMFE_MATCH_AUTO;
+    p->reserved0 = 0;
     return SLAMFE_OK;
 }
 
@@ -456,6 +458,7 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     if (p.max_keypoints >= SLAMFE_MAX_TRAIN) return SLAMFE_E_INVALID;
     if (p.frame_slots <= 0) p.frame_slots = 2 * p.max_batch > 4 ? 2 * p.max_batch : 4;
     if (p.frame_slots < p.max_batch) return SLAMFE_E_INVALID;
+    if (p.match_kernel < SLAMFE_MATCH_AUTO || p.match_kernel > SLAMFE_MATCH_MATRIX) return SLAMFE_E_INVALID;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p.device_id < 0 ||
@@ -506,7 +509,7 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     HIPCHK(c, hipMemset(c->kp_count, 0, S * sizeof(int32_t)));
     HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, (B > 16 ? B : 16) * sizeof(int32_t), 0));
     HIPCHK(c, hipMalloc(&c->match_out, K * sizeof(slamfe_match2)));
-    slamfe_match_plan(c->max_kp, c->max_kp, 1, &c->fm_qpt, &c->fm_chunk, &c->fm_nchunks);
+    slamfe_match_plan(c->max_kp, c->max_kp, 1, c->p.match_kernel, &c->fm_qpt, &c->fm_chunk, &c->fm_nchunks);
     int rc = grow(c, c->match_part, (size_t)c->fm_nchunks * K * 8);
     if (rc) return rc;
     if (p.map_capacity > 0) {
@@ -702,7 +705,7 @@ int slamfe_match_knn2(slamfe_ctx* c, const uint8_t* query, int nq, const uint8_t
     if ((rc = grow(c, c->match_t, (size_t)(nt > 0 ? nt : 1) * 32))) return rc;
     if ((rc = grow(c, c->match_o, (size_t)nq * sizeof(slamfe_match2)))) return rc;
     int qpt, chunk, nchunks;
-    slamfe_match_plan(nq, nt, 1, &qpt, &chunk, &nchunks);
+    slamfe_match_plan(nq, nt, 1, c->p.match_kernel, &qpt, &chunk, &nchunks);
     if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
     const size_t oq = 0, ot = align256((size_t)nq * 32), oo = ot + align256((size_t)nt * 32);
     if ((rc = pin_reserve(c, oo + (size_t)nq * sizeof(slamfe_match2)))) return rc;
@@ -746,7 +749,7 @@ int slamfe_match_resident_batch(slamfe_ctx* c, uint64_t first_query, uint64_t fi
         if (slot_of(c, first_query + (uint64_t)i) < 0 || slot_of(c, first_train + (uint64_t)i) < 0)
             return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown (pair %d)", i);
     int qpt, chunk, nchunks;
-    slamfe_match_plan(c->max_kp, c->max_kp, npairs, &qpt, &chunk, &nchunks);
+    slamfe_match_plan(c->max_kp, c->max_kp, npairs, c->p.match_kernel, &qpt, &chunk, &nchunks);
     int rc = grow(c, c->match_part, (size_t)npairs * nchunks * c->max_kp * 8);
     if (rc) return rc;
     KCHK(c, slamfe_launch_match(c->stream, c->desc, 0, c->kp_count, c->desc, 0, c->kp_count, c->max_kp,
@@ -795,7 +798,7 @@ int slamfe_match_shard_keys(slamfe_ctx* c, const void* d_query, int nq, const vo
                     SLAMFE_MAX_TRAIN - 1);
     if (nq == 0) return SLAMFE_OK;
     int qpt, chunk, nchunks, rc;
-    slamfe_match_plan(nq, nt, 1, &qpt, &chunk, &nchunks);
+    slamfe_match_plan(nq, nt, 1, c->p.match_kernel, &qpt, &chunk, &nchunks);
     if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
     KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)d_query, nq, nullptr,
                                 (const uint8_t*)d_train, nt, nullptr, nq, qpt, chunk, nchunks,
@@ -1084,7 +1087,7 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
             break;
         case SLAMFE_STAGE_MATCH: {
             int np = nframes > 1 ? nframes - 1 : 1, qpt, chunk, nchunks;
-            slamfe_match_plan(c->max_kp, c->max_kp, np, &qpt, &chunk, &nchunks);
+            slamfe_match_plan(c->max_kp, c->max_kp, np, c->p.match_kernel, &qpt, &chunk, &nchunks);
             int rc = grow(c, c->match_part, (size_t)np * nchunks * c->max_kp * 8);
             if (rc) return rc;
             rc = grow(c, c->match_o, (size_t)nframes * c->max_kp * sizeof(slamfe_match2));

@@ -36,7 +36,7 @@ int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes,
 /* Choose queries per lane and the train chunking for a match of at most
  * nq_max x nt_max rows (npairs independent pairs in one launch); the partial
  * buffer needs npairs * nchunks * cap * 8 bytes. */
-int slamfe_match_plan(int nq_max, int nt_max, int npairs, int* qpt, int* chunk_rows,
+int slamfe_match_plan(int nq_max, int nt_max, int npairs, int kernel, int* qpt, int* chunk_rows,
                       int* nchunks);
 int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int32_t* d_nq,
                         const uint8_t* d_train, int nt, const int32_t* d_nt, int cap, int qpt,

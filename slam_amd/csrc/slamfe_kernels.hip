@@ -1917,14 +1917,15 @@ int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes,
     return 0;
 }
 
-int slamfe_match_plan(int nq_max, int nt_max, int npairs, int* qpt, int* chunk_rows, int* nchunks)
+int slamfe_match_plan(int nq_max, int nt_max, int npairs, int kernel, int* qpt, int* chunk_rows,
+                      int* nchunks)
 {
     if (npairs < 1) npairs = 1;
     long long qblocks = (nq_max + 255) / 256;
     if (qblocks < 1) qblocks = 1;
     const long long have = qblocks * npairs;
     int rows, q;
-    if (nq_max >= 128) {
+    if (kernel == SLAMFE_MATCH_MATRIX || (kernel == SLAMFE_MATCH_AUTO && nq_max >= 128)) {
         // matrix-core kernel: a workgroup expands its 256 queries once (about the
         // cost of three tiles), so chunks are long: 2048 rows for large train sets,
         // 1024 for frame pairs (measured best on MI355X), less only when that

@@ -44,7 +44,7 @@ def test_every_entry_point_cites_the_reference_or_says_it_has_no_counterpart():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(abi.Params) == 4 * 16 + 8
+    assert C.sizeof(abi.Params) == 4 * 16 + 8 + 8
     assert abi.KEYPOINT_DTYPE.itemsize == 28 and abi.MATCH2_DTYPE.itemsize == 16
     lib = _lib.load()
     p = abi.Params()

@@ -219,6 +219,21 @@ def test_match_extreme_descriptors(fe_orb):
     assert far["d0"][0] == 256 and far["d1"][0] == 256 and far["idx0"][0] == 0
 
 
+@pytest.mark.parametrize("kernel", [abi.MATCH_POPCOUNT, abi.MATCH_MATRIX])
+def test_match_either_kernel_forced(kernel):
+    # the vector-ALU popcount kernel and the matrix-core kernel, each forced for
+    # query counts on both sides of the automatic switch
+    from slam_amd.frontend import FrontEnd
+    with FrontEnd(mode=abi.MODE_ORB, nfeatures=500, max_width=320, max_height=240, map_capacity=0,
+                  match_kernel=kernel) as fe:
+        for nq, nt in ((40, 3000), (2000, 2000), (700, 1), (257, 4099)):
+            q, t = synth.descriptor_sets(nq, nt, seed=11 + nq, dup_percent=3)
+            got = fe.knn_match(q, t)
+            want = O.match_knn2(q, t)
+            for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+                assert np.array_equal(got[name], want[name]), (kernel, nq, nt, name)
+
+
 def test_match_empty_query(fe_orb):
     assert len(fe_orb.knn_match(np.zeros((0, 32), np.uint8), np.zeros((4, 32), np.uint8))) == 0
 
