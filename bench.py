@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--streams", type=int, default=1,
                     help="independent frame streams per GPU, each with its own context and HIP stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -71,6 +71,11 @@ __device__ __forceinline__ int wave_sum(int x)
            __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 }
 
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // ---------------------------------------------------------------------------
 // K1  frame ingest: gray copy or BGR -> gray into pyramid level 0
 //     (cv::cvtColor(frame, frame, COLOR_BGR2GRAY), Init.cc:75)
@@ -367,11 +372,12 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         }
     }
 
-    // ---- FAST pass B: pretest on the tile + 1-px ring, 4 pixels per task.
-    // Task = (score row sy of 18, dword column m of 18); its pixels are LDS
-    // bytes lx = 4m .. 4m+3 of row ly = sy + 3.  Bytes are widened to two
-    // 16-bit pairs (pixels 0,2 and 1,3) so that packed 16-bit min / max / sub
+    // ---- FAST pass B: pretest on the tile + 1-px ring, 8 pixels per task.
+    // Task = (score row sy of 18, dword pair m of 9); its pixels are LDS bytes
+    // lx = 8m .. 8m+7 of row ly = sy + 3.  Bytes are widened to 16-bit pairs
+    // (pixels 0,2 and 1,3 of a dword) so that packed 16-bit min / max / sub
     // handle two pixels per operation; a negative difference flags a survivor.
+    // (162 tasks: three wave passes; with 4 pixels per task it took six.)
     {
         typedef short v2s __attribute__((ext_vector_type(2)));
         union pk { uint32_t u; v2s v; };
@@ -379,14 +385,10 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         // tiles that lie entirely in the discarded border band skip FAST
         const bool any_fast = x0 + TW + 1 > blo && x0 - 1 < L.w - blo && y0 + TH + 1 > blo &&
                               y0 - 1 < L.h - blo;
-        for (int i = tid; any_fast && i < FS_H * FB_COLD; i += 256) {
-            int sy = i / FB_COLD, m = i - sy * FB_COLD;
-            int ly = sy + 3;
-            const uint32_t* row = &tile32[ly * FL_WD + FL_X0 / 4 + m];
-            uint32_t C = row[0], Cp = row[-1], Cn = row[1];
-            uint32_t U = row[-3 * FL_WD], D = row[3 * FL_WD];
-            uint32_t L3 = __builtin_amdgcn_alignbyte(C, Cp, 1); // pixels at x-3
-            uint32_t R3 = __builtin_amdgcn_alignbyte(Cn, C, 3); // pixels at x+3
+        const v2s t2 = {(short)thr, (short)thr};
+        // survivors among the 4 pixels of dword C (ring pixels: U above, D below,
+        // L3 / R3 three to the left / right), one flag bit per pixel
+        auto pretest4 = [&](uint32_t C, uint32_t U, uint32_t D, uint32_t L3, uint32_t R3) -> uint32_t {
             uint32_t flags = 0;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -403,7 +405,6 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                                                    __builtin_elementwise_max(p4.v, p12.v));
                 v2s lo = __builtin_elementwise_max(__builtin_elementwise_min(p0.v, p8.v),
                                                    __builtin_elementwise_min(p4.v, p12.v));
-                v2s t2 = {(short)thr, (short)thr};
                 pk r1, r2;
                 r1.v = (v.v + t2) - hi; // < 0  <=>  hi > v + t
                 r2.v = lo - (v.v - t2); // < 0  <=>  lo < v - t
@@ -412,49 +413,61 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                 flags |= ((neg >> 15) & 1u) << half;
                 flags |= (neg >> 31) << (2 + half);
             }
-            // pixel k is a score position iff lx = 4m+k in [3, 68] and the image
+            return flags;
+        };
+        for (int i = tid; any_fast && i < FS_H * (FB_COLD / 2); i += 256) {
+            int sy = i / (FB_COLD / 2), m = i - sy * (FB_COLD / 2);
+            int ly = sy + 3;
+            const uint32_t* row = &tile32[ly * FL_WD + FL_X0 / 4 + 2 * m];
+            uint32_t C0 = row[0], C1 = row[1], Cp = row[-1], Cn = row[2];
+            uint32_t U0 = row[-3 * FL_WD], U1 = row[-3 * FL_WD + 1];
+            uint32_t D0 = row[3 * FL_WD], D1 = row[3 * FL_WD + 1];
+            uint32_t flags = pretest4(C0, U0, D0, __builtin_amdgcn_alignbyte(C0, Cp, 1),
+                                      __builtin_amdgcn_alignbyte(C1, C0, 3)) |
+                             pretest4(C1, U1, D1, __builtin_amdgcn_alignbyte(C1, C0, 1),
+                                      __builtin_amdgcn_alignbyte(Cn, C1, 3)) << 4;
+            // pixel k is a score position iff lx = 8m+k in [3, 68] and the image
             // position is inside the band that can still yield a keypoint:
             // keypoints outside [edge, w-edge) x [edge, h-edge) are discarded by
             // the ORB border filter, and NMS looks one pixel further, so scores
             // are needed on [lo, w-lo) x [lo, h-lo) with lo = max(3, edge-1)
-            int gy = y0 - 1 + sy, gxb = x0 - 4 + 4 * m;
-            int kmin = max(3 - 4 * m, blo - gxb), kmax = min(FS_W + 2 - 4 * m, L.w - blo - 1 - gxb);
+            int gy = y0 - 1 + sy, gxb = x0 - 4 + 8 * m;
+            int kmin = max(3 - 8 * m, blo - gxb), kmax = min(FS_W + 2 - 8 * m, L.w - blo - 1 - gxb);
             kmin = max(kmin, 0);
-            kmax = min(kmax, 3);
+            kmax = min(kmax, 7);
             uint32_t valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
                                  ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
             flags &= valid;
             // wave-level compaction: exclusive prefix of the per-lane counts
-            // (0..4) from three ballots, one LDS atomic per wave
+            // (0..8) from four ballots, one LDS atomic per wave
             const uint32_t c = (uint32_t)__popc(flags);
-            const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u);
+            const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u),
+                                     m3 = __ballot(c & 8u);
             const unsigned long long act = __ballot(1);
-            uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
-                           2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)) +
-                           4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-            const uint32_t tot = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) + 4u * (uint32_t)__popcll(m2);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+            uint32_t pre = lane_rank(m0) + 2u * lane_rank(m1) + 4u * lane_rank(m2) + 8u * lane_rank(m3);
+            const uint32_t tot = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) +
+                                 4u * (uint32_t)__popcll(m2) + 8u * (uint32_t)__popcll(m3);
+            const uint32_t rank = lane_rank(act);
             uint32_t base = 0;
             if (tot) { // wave-uniform
                 if (rank == 0) base = atomicAdd(&npos, tot);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + pre;
-                int sbase = sy * FS_W + 4 * m - 3;
+                int sbase = sy * FS_W + 8 * m - 3;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 8; ++k)
                     if (flags & (1u << k)) pos[base++] = (uint16_t)(sbase + k);
             }
         }
     }
 
-    // ---- blur row pass: task = (row r of 22, group k of 16) -> 4 sums
+    // ---- blur row pass: task = (row r of 22, group k of 8) -> 8 sums
+    // (176 tasks: three wave passes)
     {
         const uint32_t KA = 18u | (34u << 8) | (49u << 16) | (55u << 24); // taps 0..3
         const uint32_t KB = 49u | (34u << 8) | (18u << 16);               // taps 4..6, 0
-        for (int i = tid; i < BR_H * 16; i += 256) {
-            int r = i >> 4, k = i & 15;
-            const uint32_t* p = &tile32[(r + 1) * FL_WD + FL_X0 / 4 + k]; // columns x0-4+4k .. +11
-            uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-            // output c = 4k+j reads bytes (j+1 .. j+7) of the 12-byte window
+        // the 4 sums of the dword whose window is (d0, d1, d2): output c = 4k+j reads
+        // bytes (j+1 .. j+7) of the 12-byte window
+        auto rows4 = [&](uint32_t d0, uint32_t d1, uint32_t d2) -> uint2 {
             uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0, false);
             s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, s0, false);
             uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0, false);
@@ -464,8 +477,14 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             uint32_t s3 = __builtin_amdgcn_udot4(d1, KA, 0, false);
             s3 = __builtin_amdgcn_udot4(d2, KB, s3, false);
             // sums are <= 257 * 255 = 65535: two per dword
-            uint2 o = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
-            *reinterpret_cast<uint2*>(&rows32[r * (TW / 2) + 2 * k]) = o;
+            return make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+        };
+        for (int i = tid; i < BR_H * 8; i += 256) {
+            int r = i >> 3, k = i & 7;
+            const uint32_t* p = &tile32[(r + 1) * FL_WD + FL_X0 / 4 + 2 * k]; // columns x0-4+8k .. +15
+            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+            uint2 a = rows4(d0, d1, d2), c = rows4(d1, d2, d3);
+            *reinterpret_cast<uint4*>(&rows32[r * (TW / 2) + 4 * k]) = make_uint4(a.x, a.y, c.x, c.y);
         }
     }
     __syncthreads();
@@ -566,10 +585,6 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
 
 // The candidate lists of one band (a row of tiles), walked by one wavefront: a
 // lane owns slots 4*lane .. 4*lane+3 of every tile's list (one 16-byte load),
