@@ -195,54 +195,103 @@ __device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
     return c.v;
 }
 
+// A wavefront produces RS_ROWS consecutive destination rows.  Everything that
+// depends on the column only (source offset, byte selection, tap weights of the
+// lane's 4 pixels) is decoded once per column block; the horizontal pass of a
+// source row (4 values of 8.8 fixed point, two dwords) is computed once and used
+// by both destination rows that blend it (consecutive destination rows share a
+// source row: 1.2 source rows per destination row instead of 2).
+#define RS_ROWS 4
+
 __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nframes,
                                                 uint8_t* __restrict__ pyr,
                                                 const uint32_t* __restrict__ taps)
 {
     const slamfe_dev_level& S = g.lv[l - 1];
     const slamfe_dev_level& D = g.lv[l];
-    const int y = wg_item() * 4 + (threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int y_first = (wg_item() * 4 + wv) * RS_ROWS;
     const int f = wg_frame();
-    if (f >= nframes || y >= D.h) return;
-    for (int x = (threadIdx.x & 63) * 4; x < D.w; x += 256) {
+    if (f >= nframes || y_first >= D.h) return;
+    const int y_end = min(y_first + RS_ROWS, D.h);
     const uint8_t* src = pyr + (size_t)f * g.frame_bytes + S.off;
     uint8_t* dst = pyr + (size_t)f * g.frame_bytes + D.off;
-    // the tap table is padded with zero entries to a multiple of 4 per level
-    const uint4 tx = *reinterpret_cast<const uint4*>(taps + D.tap_x + x);
-    const uint32_t ty = taps[D.tap_y + y];
-    const uint32_t txs[4] = {tx.x, tx.y, tx.z, tx.w};
-    const uint32_t yo = ty & 0xffffu, w1 = ty >> 16, w0 = 256u - w1;
-    const uint32_t yo1 = yo + (w1 ? 1u : 0u);
-    const uint32_t a = (txs[0] & 0xffffu) & ~3u;
-    const uint32_t* r0 = reinterpret_cast<const uint32_t*>(src + (size_t)yo * S.pitch + a);
-    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(src + (size_t)yo1 * S.pitch + a);
-    // 12 source bytes per row; bytes past the row end are read but carry weight 0
-    const uint32_t p0[3] = {r0[0], r0[1], r0[2]};
-    const uint32_t p1[3] = {r1[0], r1[1], r1[2]};
-    const slamfe_us2 wv = as_us2(w0 | (w1 << 16));
-    uint32_t out = 0;
+    const int spitch = S.pitch, dpitch = D.pitch;
+    for (int x = (threadIdx.x & 63) * 4; x < D.w; x += 256) {
+        // the tap table is padded with zero entries to a multiple of 4 per level
+        const uint4 tx = *reinterpret_cast<const uint4*>(taps + D.tap_x + x);
+        const uint32_t txs[4] = {tx.x, tx.y, tx.z, tx.w};
+        const uint32_t a = (txs[0] & 0xffffu) & ~3u; // aligned start of the 12 source bytes
+        uint32_t sh[4], sel[4];
+        slamfe_us2 cv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t o = (txs[k] & 0xffffu) - a; // 0 .. 10
-        const uint32_t c1 = txs[k] >> 16;
-        const slamfe_us2 cv = as_us2((256u - c1) | (c1 << 16));
-        const uint32_t sel = o >> 2;
-        uint32_t lo0 = sel == 0 ? p0[0] : (sel == 1 ? p0[1] : p0[2]);
-        uint32_t hi0 = sel == 0 ? p0[1] : (sel == 1 ? p0[2] : 0u);
-        uint32_t lo1 = sel == 0 ? p1[0] : (sel == 1 ? p1[1] : p1[2]);
-        uint32_t hi1 = sel == 0 ? p1[1] : (sel == 1 ? p1[2] : 0u);
-        uint32_t q0 = __builtin_amdgcn_alignbyte(hi0, lo0, o); // bytes o, o+1 in bits 0..15
-        uint32_t q1 = __builtin_amdgcn_alignbyte(hi1, lo1, o);
-        // widen the two taps to a 16-bit pair: 0x00 b1 0x00 b0
-        q0 = __builtin_amdgcn_perm(0u, q0, 0x0c010c00u);
-        q1 = __builtin_amdgcn_perm(0u, q1, 0x0c010c00u);
-        uint32_t h0 = __builtin_amdgcn_udot2(as_us2(q0), cv, 0u, false); // 8.8, <= 65280
-        uint32_t h1 = __builtin_amdgcn_udot2(as_us2(q1), cv, 0u, false);
-        uint32_t v = __builtin_amdgcn_udot2(as_us2(h0 | (h1 << 16)), wv, 1u << 15, false) >> 16;
-        out |= min(v, 255u) << (8 * k);
-    }
-    // rows are padded to a multiple of 64 bytes: the dword store stays in the row
-    *reinterpret_cast<uint32_t*>(dst + (size_t)y * D.pitch + x) = out;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t o = (txs[k] & 0xffffu) - a; // 0 .. 10
+            const uint32_t c1 = txs[k] >> 16;
+            cv[k] = as_us2((256u - c1) | (c1 << 16));
+            sh[k] = o;
+            sel[k] = o >> 2;
+        }
+        // horizontal pass of one source row: the 4 pixels' 8.8 values, two per dword.
+        // 12 source bytes; bytes past the row end are read but carry weight 0
+        auto hpass = [&](uint32_t p0, uint32_t p1, uint32_t p2) -> uint2 {
+            uint32_t h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t lo = sel[k] == 0 ? p0 : (sel[k] == 1 ? p1 : p2);
+                uint32_t hi = sel[k] == 0 ? p1 : (sel[k] == 1 ? p2 : 0u);
+                uint32_t q = __builtin_amdgcn_alignbyte(hi, lo, sh[k]); // bytes o, o+1 in bits 0..15
+                q = __builtin_amdgcn_perm(0u, q, 0x0c010c00u);          // widen: 0x00 b1 0x00 b0
+                h[k] = __builtin_amdgcn_udot2(as_us2(q), cv[k], 0u, false); // 8.8, <= 65280
+            }
+            return make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        };
+        // walk the source rows the strip needs in order; the next row's 12 bytes are
+        // requested before the current row is processed
+        int y = y_first;
+        uint32_t ty = taps[D.tap_y + y];
+        int yo = (int)(ty & 0xffffu);
+        uint32_t w1 = ty >> 16;
+        int yo1 = yo + (w1 ? 1 : 0);
+        int sy = yo;
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(src + (size_t)sy * spitch + a);
+        uint32_t p0 = r[0], p1 = r[1], p2 = r[2];
+        uint2 Hprev = make_uint2(0, 0), Hcur = make_uint2(0, 0);
+        while (y < y_end) { // uniform
+            const int nsy = min(sy + 1, S.h - 1);
+            const uint32_t* rn = reinterpret_cast<const uint32_t*>(src + (size_t)nsy * spitch + a);
+            const uint32_t n0 = rn[0], n1 = rn[1], n2 = rn[2];
+            Hprev = Hcur;
+            Hcur = hpass(p0, p1, p2);
+            while (y < y_end && yo1 == sy) { // destination rows whose second source row is sy
+                const uint2 H0 = yo == sy ? Hcur : Hprev;
+                const slamfe_us2 wv2 = as_us2((256u - w1) | (w1 << 16));
+                // pair the two rows' values of each pixel: (h0, h1) -> one v_dot2 with the
+                // rounding constant as the addend: out = (h0*w0 + h1*w1 + 2^15) >> 16
+                const uint32_t e0 = __builtin_amdgcn_perm(Hcur.x, H0.x, 0x05040100u); // px0: low halves
+                const uint32_t e1 = __builtin_amdgcn_perm(Hcur.x, H0.x, 0x07060302u); // px1: high halves
+                const uint32_t e2 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x05040100u);
+                const uint32_t e3 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x07060302u);
+                uint32_t v0 = __builtin_amdgcn_udot2(as_us2(e0), wv2, 1u << 15, false) >> 16;
+                uint32_t v1 = __builtin_amdgcn_udot2(as_us2(e1), wv2, 1u << 15, false) >> 16;
+                uint32_t v2 = __builtin_amdgcn_udot2(as_us2(e2), wv2, 1u << 15, false) >> 16;
+                uint32_t v3 = __builtin_amdgcn_udot2(as_us2(e3), wv2, 1u << 15, false) >> 16;
+                const uint32_t out = min(v0, 255u) | (min(v1, 255u) << 8) | (min(v2, 255u) << 16) |
+                                     (min(v3, 255u) << 24);
+                // rows are padded to a multiple of 64 bytes: the dword store stays in the row
+                *reinterpret_cast<uint32_t*>(dst + (size_t)y * dpitch + x) = out;
+                if (++y < y_end) {
+                    ty = taps[D.tap_y + y];
+                    yo = (int)(ty & 0xffffu);
+                    w1 = ty >> 16;
+                    yo1 = yo + (w1 ? 1 : 0);
+                }
+            }
+            ++sy;
+            p0 = n0;
+            p1 = n1;
+            p2 = n2;
+        }
     }
 }
 
@@ -1856,7 +1905,7 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
                           const uint32_t* taps)
 {
     for (int l = 1; l < g.nlevels; ++l) {
-        hipLaunchKernelGGL(k_resize, frame_grid((g.lv[l].h + 3) / 4, nframes), dim3(256), 0, s, g, l,
+        hipLaunchKernelGGL(k_resize, frame_grid((g.lv[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nframes), dim3(256), 0, s, g, l,
                            nframes, pyr, taps);
         LAUNCH_CHECK();
     }
