@@ -225,7 +225,12 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(hbm_stage)
+            tj = json.load(open(tpath))
+            # measured on launches of tj["frames_per_launch"] frames; traffic is
+            # per frame-proportional, scaled to this run's batch
+            traffic = tj.get(hbm_stage)
+            if traffic is not None:
+                traffic = int(traffic * B / tj.get("frames_per_launch", B))
         except Exception:
             traffic = None
     roofline = {"kernel": "k_" + hbm_stage if hbm_stage != "pyramid" else "k_resize (7 launches)",
