@@ -732,6 +732,7 @@ int slamfe_match_resident(slamfe_ctx* c, uint64_t query_frame, uint64_t train_fr
                           slamfe_match2* d_out)
 {
     if (!c || !d_out) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
     int sq = slot_of(c, query_frame), st = slot_of(c, train_frame);
     if (sq < 0 || st < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown");
     KCHK(c, slamfe_launch_match(c->stream, c->desc + (size_t)sq * c->max_kp * 32, 0, c->kp_count + sq,
@@ -745,6 +746,7 @@ int slamfe_match_resident_batch(slamfe_ctx* c, uint64_t first_query, uint64_t fi
                                 slamfe_match2* d_out)
 {
     if (!c || !d_out || npairs < 1 || npairs > c->nslots) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
     for (int i = 0; i < npairs; ++i)
         if (slot_of(c, first_query + (uint64_t)i) < 0 || slot_of(c, first_train + (uint64_t)i) < 0)
             return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown (pair %d)", i);
@@ -797,6 +799,7 @@ int slamfe_match_shard_keys(slamfe_ctx* c, const void* d_query, int nq, const vo
         return fail(c, SLAMFE_E_INVALID, "shard of %d rows; at most %d per call", nt,
                     SLAMFE_MAX_TRAIN - 1);
     if (nq == 0) return SLAMFE_OK;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
     int qpt, chunk, nchunks, rc;
     slamfe_match_plan(nq, nt, 1, c->p.match_kernel, &qpt, &chunk, &nchunks);
     if ((rc = grow(c, c->match_part, (size_t)nchunks * nq * 8))) return rc;
@@ -811,6 +814,7 @@ int slamfe_merge_shard_keys(slamfe_ctx* c, const uint64_t* d_keys_all, int nshar
                             slamfe_match2* d_out)
 {
     if (!c || !d_keys_all || !d_out || nshards < 1 || nq < 0) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
     KCHK(c, slamfe_launch_merge_shard_keys(c->stream, d_keys_all, nshards, nq, c->p.ratio, d_out));
     return SLAMFE_OK;
 }
