@@ -434,6 +434,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         // tiles that lie entirely in the discarded border band skip FAST
         const bool any_fast = x0 + TW + 1 > blo && x0 - 1 < L.w - blo && y0 + TH + 1 > blo &&
                               y0 - 1 < L.h - blo;
+        const bool interior = x0 - 1 >= blo && x0 + TW <= L.w - blo - 1 && y0 - 1 >= blo &&
+                              y0 + TH <= L.h - blo - 1;
         const v2s t2 = {(short)thr, (short)thr};
         // survivors among the 4 pixels of dword C (ring pixels: U above, D below,
         // L3 / R3 three to the left / right), one flag bit per pixel
@@ -445,10 +447,12 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                 if (half == 0) {
                     v.u = C & 0x00ff00ffu; p0.u = D & 0x00ff00ffu; p8.u = U & 0x00ff00ffu;
                     p4.u = R3 & 0x00ff00ffu; p12.u = L3 & 0x00ff00ffu;
-                } else {
-                    v.u = (C >> 8) & 0x00ff00ffu; p0.u = (D >> 8) & 0x00ff00ffu;
-                    p8.u = (U >> 8) & 0x00ff00ffu; p4.u = (R3 >> 8) & 0x00ff00ffu;
-                    p12.u = (L3 >> 8) & 0x00ff00ffu;
+                } else { // bytes 1 and 3, widened by one v_perm each
+                    v.u = __builtin_amdgcn_perm(0u, C, 0x0c030c01u);
+                    p0.u = __builtin_amdgcn_perm(0u, D, 0x0c030c01u);
+                    p8.u = __builtin_amdgcn_perm(0u, U, 0x0c030c01u);
+                    p4.u = __builtin_amdgcn_perm(0u, R3, 0x0c030c01u);
+                    p12.u = __builtin_amdgcn_perm(0u, L3, 0x0c030c01u);
                 }
                 v2s hi = __builtin_elementwise_min(__builtin_elementwise_max(p0.v, p8.v),
                                                    __builtin_elementwise_max(p4.v, p12.v));
@@ -480,15 +484,23 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             // keypoints outside [edge, w-edge) x [edge, h-edge) are discarded by
             // the ORB border filter, and NMS looks one pixel further, so scores
             // are needed on [lo, w-lo) x [lo, h-lo) with lo = max(3, edge-1)
-            int gy = y0 - 1 + sy, gxb = x0 - 4 + 8 * m;
-            int kmin = max(3 - 8 * m, blo - gxb), kmax = min(FS_W + 2 - 8 * m, L.w - blo - 1 - gxb);
-            kmin = max(kmin, 0);
-            kmax = min(kmax, 7);
-            uint32_t valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
-                                 ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
+            // (tiles whose score area lies inside that band need the column rule only)
+            uint32_t valid;
+            if (interior) { // uniform
+                valid = m == 0 ? 0xf8u : (m == FB_COLD / 2 - 1 ? 0x1fu : 0xffu);
+            } else {
+                int gy = y0 - 1 + sy, gxb = x0 - 4 + 8 * m;
+                int kmin = max(3 - 8 * m, blo - gxb), kmax = min(FS_W + 2 - 8 * m, L.w - blo - 1 - gxb);
+                kmin = max(kmin, 0);
+                kmax = min(kmax, 7);
+                valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
+                            ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
+            }
             flags &= valid;
             // wave-level compaction: exclusive prefix of the per-lane counts
-            // (0..8) from four ballots, one LDS atomic per wave
+            // (0..8) from four ballots, one LDS atomic per wave.  (A per-lane
+            // atomicAdd of the count is turned by the compiler into a serial
+            // loop over the lanes and made the kernel 12 % slower.)
             const uint32_t c = (uint32_t)__popc(flags);
             const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u),
                                      m3 = __ballot(c & 8u);
