@@ -47,6 +47,20 @@ def build():
     kr, dr = O.extract(abi.reference_params(mode=abi.MODE_PROVIDED, fast_threshold=30), kitti)
     out["kitti_ref_count"] = np.array([len(kr)])
     out["kitti_ref_sha"] = np.array([sha(kr), sha(dr)])
+    # frame ingest (resize 0.99 on BGR), reprojection and the projection search
+    g = synth.textured_canvas(200, 160, 31)
+    bgr = np.ascontiguousarray(np.stack([np.roll(g, 1, 0), g, np.roll(g, 2, 1)], axis=2))
+    small_resized = O.resize_linear_8u(bgr, 0.99, 0.99)
+    out["resize_small"] = small_resized
+    k, d = O.extract(p_orb, small_resized)
+    out["resize_small_kps"], out["resize_small_desc"] = k, d
+    pose, K, xyz, th = synth.camera_scene(400, 640, 480, 8)
+    uv, idx = O.reproject(pose, K, xyz, th, 640, 480)
+    out["reproject_uv"], out["reproject_idx"] = uv, idx
+    xy = np.stack([ka["x"], ka["y"]], 1)
+    muv, mdesc = synth.local_map(da, xy, 500, 640, 480, seed=4)
+    kp_idx = np.arange(0, len(ka), 3, dtype=np.int32)
+    out["search_hits"] = O.search_by_projection(xy, da, kp_idx, muv, mdesc, np.arange(500, dtype=np.int32))
     return out
 
 

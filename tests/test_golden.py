@@ -37,6 +37,54 @@ def test_checker_reproduces_golden_hashes():
                                       sha(np.stack([m["idx0"], m["idx1"]])), sha(m["ratio_pass"])]
 
 
+def _new_row_inputs():
+    g = synth.textured_canvas(200, 160, 31)
+    bgr = np.ascontiguousarray(np.stack([np.roll(g, 1, 0), g, np.roll(g, 2, 1)], axis=2))
+    scene = synth.camera_scene(400, 640, 480, 8)
+    return bgr, scene
+
+
+def test_checker_reproduces_golden_ingest_reprojection_search():
+    bgr, (pose, K, xyz, th) = _new_row_inputs()
+    resized = O.resize_linear_8u(bgr, 0.99, 0.99)
+    assert np.array_equal(resized, G["resize_small"])
+    k, d = O.extract(abi.reference_params(fast_threshold=20, nfeatures=60), resized)
+    assert np.array_equal(k, G["resize_small_kps"]) and np.array_equal(d, G["resize_small_desc"])
+    uv, idx = O.reproject(pose, K, xyz, th, 640, 480)
+    assert np.array_equal(uv, G["reproject_uv"]) and np.array_equal(idx, G["reproject_idx"])
+    a, _ = synth.frame_pair(640, 480)
+    ka, da = O.extract(abi.reference_params(fast_threshold=20, nfeatures=2000), a)
+    xy = np.stack([ka["x"], ka["y"]], 1)
+    muv, mdesc = synth.local_map(da, xy, 500, 640, 480, seed=4)
+    kp_idx = np.arange(0, len(ka), 3, dtype=np.int32)
+    hits = O.search_by_projection(xy, da, kp_idx, muv, mdesc, np.arange(500, dtype=np.int32))
+    assert np.array_equal(hits, G["search_hits"]) and (hits >= 0).sum() > 50
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_ingest_reprojection_search():
+    from slam_amd.frontend import FrontEnd
+    bgr, (pose, K, xyz, th) = _new_row_inputs()
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=60, max_width=640, max_height=480,
+                  map_capacity=1024) as fe:
+        f, resized = fe.extract_scaled_bgr(bgr, 0.99, 0.99)
+        assert np.array_equal(resized, G["resize_small"])
+        assert np.array_equal(f.keypoints, G["resize_small_kps"])
+        assert np.array_equal(f.descriptors, G["resize_small_desc"])
+        fe.map_put_xyz(np.arange(len(xyz)), xyz)
+        uv, idx = fe.reproject(pose, K, th, 640, 480, len(xyz))
+        assert np.array_equal(uv, G["reproject_uv"]) and np.array_equal(idx, G["reproject_idx"])
+    a, _ = synth.frame_pair(640, 480)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=2000, max_width=640, max_height=480,
+                  map_capacity=1024) as fe:
+        fa = fe.extract_keypoints(a)
+        muv, mdesc = synth.local_map(fa.descriptors, fa.pt, 500, 640, 480, seed=4)
+        fe.map_put(np.arange(500), mdesc)
+        kp_idx = np.arange(0, len(fa), 3, dtype=np.int32)
+        hits = fe.search_by_projection(fa, kp_idx, muv, np.arange(500, dtype=np.int32))
+        assert np.array_equal(hits, G["search_hits"])
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_golden():
     from slam_amd.frontend import FrontEnd
