@@ -1749,6 +1749,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(
 }
 
 #define PROJ_CHUNK 64 /* inliers per staged chunk */
+#define PROJ_STRIDE (PROJ_K + 1) /* LDS words per staged list: odd, so lanes hit different banks */
 
 __global__ __launch_bounds__(256) void k_proj_resolve(
     const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
@@ -1757,13 +1758,23 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
     float radius, int max_hamming, const uint32_t* __restrict__ cand,
     const int32_t* __restrict__ cand_n, int32_t* __restrict__ matched)
 {
-    // One workgroup of four waves.  Wave 0 walks the inliers in order (the
-    // serial part); waves 1-3 meanwhile copy the next chunk of 64 candidate
-    // lists from global memory into the other LDS buffer, so the chain never
-    // waits on HBM.  LDS: two buffers of 64*PROJ_K keys + 64 list headers,
-    // 64 answers, then one bit per visible point ((R+31)/32 words).
+    // One workgroup of four waves.  Wave 0 resolves the inliers in order, 64 at
+    // a time; waves 1-3 meanwhile copy the next chunk of 64 candidate lists from
+    // global memory into the other LDS buffer.  LDS: two buffers of 64 lists +
+    // 64 list headers, 64 answers, then one bit per visible point.
+    //
+    // The reference's loop is serial: inlier i takes its best point among those
+    // no earlier inlier took.  Lane l of wave 0 holds inlier l of the chunk and
+    // proposes the first candidate of its (sorted) list that is not taken yet.
+    // If the proposals of lanes 0..k-1 are pairwise different they are exactly
+    // what the serial loop would choose (each is the best of a superset of what
+    // the serial loop would see, and none of them is removed by an earlier
+    // lane), so that whole prefix is final at once; lane k, the first one whose
+    // proposal an earlier lane also made, proposes again in the next round.
+    // Contested points are rare, so a chunk usually takes one or two rounds
+    // instead of 64 dependent steps.
     extern __shared__ uint32_t plds[];
-    const int BUF = PROJ_CHUNK * PROJ_K + PROJ_CHUNK;
+    const int BUF = PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK;
     int32_t* res = reinterpret_cast<int32_t*>(plds + 2 * BUF);
     uint32_t* taken = plds + 2 * BUF + PROJ_CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1774,12 +1785,12 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
         const int nc = min(PROJ_CHUNK, n_inl - c0);
         if (nc <= 0) return;
         uint32_t* st = plds + buf * BUF;
-        int32_t* sn = reinterpret_cast<int32_t*>(st + PROJ_CHUNK * PROJ_K);
+        int32_t* sn = reinterpret_cast<int32_t*>(st + PROJ_CHUNK * PROJ_STRIDE);
         const int t = tid - t0;
         if (t < PROJ_CHUNK) sn[t] = t < nc ? cand_n[c0 + t] : 0;
         const uint32_t* src = cand + (size_t)c0 * PROJ_K;
 #pragma unroll 4
-        for (int e = t; e < nc * PROJ_K; e += nt) st[e] = src[e];
+        for (int e = t; e < nc * PROJ_K; e += nt) st[(e / PROJ_K) * PROJ_STRIDE + (e % PROJ_K)] = src[e];
     };
 
     load_chunk(0, 0, 0, 256);
@@ -1791,51 +1802,48 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
             load_chunk(c0 + PROJ_CHUNK, buf ^ 1, 64, 192);
         } else {
             const uint32_t* stage = plds + buf * BUF;
-            const int32_t* stage_n = reinterpret_cast<const int32_t*>(stage + PROJ_CHUNK * PROJ_K);
-            // Software-pipelined serial chain.  List headers live in a register
-            // (lane ii holds inlier ii's header, fetched with readlane); keys
-            // are read from LDS two iterations ahead and the consumed-bit of
-            // each key's point one iteration ahead, i.e. before the current
-            // inlier's choice is recorded -- that one missing update is patched
-            // by comparing against `last`.  The chain itself is ballot ->
-            // find-first -> readlane: registers only.
+            const int32_t* stage_n = reinterpret_cast<const int32_t*>(stage + PROJ_CHUNK * PROJ_STRIDE);
             volatile uint32_t* vt = taken;
-            const int cn_reg = stage_n[lane];
-            auto load_key = [&](int ii) -> uint32_t {
-                if (ii >= nc) return 0xffffffffu;
-                int c = __builtin_amdgcn_readlane(cn_reg, ii);
-                int n = c < 0 ? 0 : (c & 0xffff);
-                return lane < n ? stage[ii * PROJ_K + lane] : 0xffffffffu;
-            };
-            auto load_tk = [&](uint32_t k) -> bool {
-                if (k == 0xffffffffu) return false;
-                uint32_t j = k & 0xfffffu;
-                return (vt[j >> 5] >> (j & 31)) & 1u;
-            };
-            uint32_t key0 = load_key(0), key1 = load_key(1);
-            bool tk0 = load_tk(key0);
-            int last = -1;
-            for (int ii = 0; ii < nc; ++ii) {
-                const int i = c0 + ii;
-                const int cn = __builtin_amdgcn_readlane(cn_reg, ii);
-                const uint32_t key = key0;
-                const bool tk = tk0;
-                const uint32_t key2 = load_key(ii + 2);
-                const bool tk1 = load_tk(key1); // reads `taken` before this inlier's update
-                int result = -1; // position j of the chosen point
-                bool rescan = cn < 0;
-                if (!rescan) {
-                    const int j = (int)(key & 0xfffffu);
-                    const bool avail = key != 0xffffffffu && !tk && j != last;
-                    unsigned long long m = __ballot(avail);
-                    if (m) {
-                        int first = __ffsll((long long)m) - 1;
-                        result = (int)((uint32_t)__builtin_amdgcn_readlane((int)key, first) & 0xfffffu);
-                    } else if (cn & (1 << 30)) {
-                        rescan = true;
+            // list header: number of stored candidates; bit 30: more passed the gates
+            // than were stored; negative: never ranked (too many points for the sort)
+            const int cn = lane < nc ? stage_n[lane] : 0;
+            const int nl = cn < 0 ? 0 : (cn & 0xffff);
+            const bool overflow = cn < 0 || (cn & (1 << 30));
+            const uint32_t* mylist = stage + lane * PROJ_STRIDE;
+            int pos = 0, result = -1;
+            bool done = lane >= nc;
+            while (__ballot(!done)) { // every round finishes at least the first open lane
+                int prop = -1; // position j of the proposed point
+                bool dry = false;
+                if (!done) {
+                    while (pos < nl) {
+                        const uint32_t j = mylist[pos] & 0xfffffu;
+                        if (!((vt[j >> 5] >> (j & 31)) & 1u)) {
+                            prop = (int)j;
+                            break;
+                        }
+                        ++pos;
+                    }
+                    dry = prop < 0 && overflow; // the stored list ran out but more candidates exist
+                }
+                bool stop = dry;
+                if (__ballot(prop >= 0)) {
+#pragma unroll 7
+                    for (int d = 1; d < 64; ++d) {
+                        const int o = __shfl_up(prop, d);
+                        stop = stop || (lane >= d && prop >= 0 && o == prop);
                     }
                 }
-                if (rescan) { // the list overflowed and ran dry (or was never ranked)
+                const unsigned long long mstop = __ballot(stop && !done);
+                const int k = mstop ? __ffsll((long long)mstop) - 1 : 64;
+                if (!done && lane < k) {
+                    result = prop;
+                    if (prop >= 0) atomicOr(&taken[prop >> 5], 1u << (prop & 31));
+                    done = true;
+                }
+                if (k < 64 && __builtin_amdgcn_readlane((int)dry, k)) { // uniform
+                    // inlier k has to look at every point again: the whole wave does it
+                    const int i = c0 + k;
                     const int idx = kp_idx[i];
                     uint32_t best = 0xffffffffu;
                     if (idx >= 0 && idx < nkp) {
@@ -1852,17 +1860,18 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1)
                         best = min(best, (uint32_t)__shfl_xor((int)best, o));
-                    if (best != 0xffffffffu) result = (int)(best & 0xfffffu);
+                    const int r = best != 0xffffffffu ? (int)(best & 0xfffffu) : -1;
+                    if (lane == k) {
+                        result = r;
+                        if (r >= 0) atomicOr(&taken[r >> 5], 1u << (r & 31));
+                        done = true;
+                    }
                 }
-                if (lane == 0) {
-                    res[ii] = result;
-                    if (result >= 0) atomicOr(&taken[result >> 5], 1u << (result & 31));
-                }
-                last = result;
-                key0 = key1;
-                tk0 = tk1;
-                key1 = key2;
+                // the next round's reads of `taken` come after these updates: LDS
+                // operations of one wave execute in order
+                wave_lds_fence();
             }
+            if (lane < nc) res[lane] = result;
         }
         __syncthreads();
         if (tid < nc) {
@@ -2086,7 +2095,7 @@ int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const ui
                        reinterpret_cast<const uint32_t*>(map_desc), radius, max_hamming, cand, cand_n);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(256),
-                       (2 * (PROJ_CHUNK * PROJ_K + PROJ_CHUNK) + PROJ_CHUNK) * 4 +
+                       (2 * (PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK) + PROJ_CHUNK) * 4 +
                            ((size_t)R + 31) / 32 * 4 + 4,
                        s, kps,
                        reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
@@ -2217,7 +2226,7 @@ int slamfe_kernels_init(size_t sort_lds_bytes)
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SLAMFE_PROJ_MAX_POINTS / 8 + (2 * (PROJ_CHUNK * PROJ_K + PROJ_CHUNK) + PROJ_CHUNK) * 4 + 64);
+                            SLAMFE_PROJ_MAX_POINTS / 8 + (2 * (PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK) + PROJ_CHUNK) * 4 + 64);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
