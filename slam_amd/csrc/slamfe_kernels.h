@@ -47,7 +47,7 @@ int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int ns
                                    float ratio, slamfe_match2* d_out);
 
 #define SLAMFE_PROJ_K 32
-#define SLAMFE_PROJ_MAX_POINTS (1 << 20)
+#define SLAMFE_PROJ_MAX_POINTS (1 << 19)
 int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
                              const int32_t* kp_idx, int n_inl, const float* uv,
                              const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,

@@ -7,6 +7,8 @@
 // slamfe_math.h and must not be fused.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <math.h>
+#include <string.h>
 #include <stdint.h>
 
 #include "slamfe.h"
@@ -1674,12 +1676,17 @@ __global__ __launch_bounds__(256) void k_merge_shard_keys(const uint64_t* __rest
 #define PROJ_K 32
 #define PROJ_LDS 2048
 
-__device__ __forceinline__ bool proj_gate(float ux, float uy, float kx, float ky, float radius)
+// The pixel-distance gate of Init.cc:389-391 and Init.cc:242: float differences,
+// squares and sum in double, square root narrowed to float, compared with the
+// radius.  Root and narrowing are monotone, so the test is dd <= gate_dd with
+// gate_dd = the largest double whose narrowed root does not exceed the radius
+// (found on the host by bisection over the doubles, slamfe_proj_gate_threshold):
+// same decisions, no square root per pair.
+__device__ __forceinline__ bool proj_gate(float ux, float uy, float kx, float ky, double gate_dd)
 {
     float dx = ux - kx, dy = uy - ky;
     double dd = (double)dx * (double)dx + (double)dy * (double)dy;
-    float e = (float)sqrt(dd);
-    return e <= radius;
+    return dd <= gate_dd;
 }
 
 __device__ __forceinline__ int hamming256_dev(const uint32_t* __restrict__ a,
@@ -1696,7 +1703,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(
     const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
     const int32_t* __restrict__ kp_idx, int n_inl, const float2* __restrict__ uv,
     const int32_t* __restrict__ point_ids, int R, const uint32_t* __restrict__ map_desc,
-    float radius, int max_hamming, uint32_t* __restrict__ cand_out, int32_t* __restrict__ cand_n)
+    double gate_dd, int max_hamming, uint32_t* __restrict__ cand_out, int32_t* __restrict__ cand_n)
 {
     __shared__ uint32_t lds[PROJ_LDS];
     __shared__ uint32_t cnt;
@@ -1707,13 +1714,23 @@ __global__ __launch_bounds__(256) void k_proj_candidates(
     if (idx >= 0 && idx < nkp) {
         const float kx = kps[idx].x, ky = kps[idx].y;
         const uint32_t* qd = fdesc + (size_t)idx * 8;
-        for (int j = tid; j < R; j += 256) {
-            float2 p = uv[j];
-            if (proj_gate(p.x, p.y, kx, ky, radius)) {
-                int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
-                if (h <= max_hamming) {
-                    uint32_t pos = atomicAdd(&cnt, 1u);
-                    if (pos < PROJ_LDS) lds[pos] = ((uint32_t)h << 20) | (uint32_t)j;
+        // four positions per step so that the loads are in flight together
+        for (int j0 = tid; j0 < R; j0 += 4 * 256) {
+            float2 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                p[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                if (j < R && proj_gate(p[u].x, p[u].y, kx, ky, gate_dd)) {
+                    int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
+                    if (h <= max_hamming) {
+                        uint32_t pos = atomicAdd(&cnt, 1u);
+                        if (pos < PROJ_LDS) lds[pos] = ((uint32_t)h << 20) | (uint32_t)j;
+                    }
                 }
             }
         }
@@ -1750,12 +1767,13 @@ __global__ __launch_bounds__(256) void k_proj_candidates(
 
 #define PROJ_CHUNK 64 /* inliers per staged chunk */
 #define PROJ_STRIDE (PROJ_K + 1) /* LDS words per staged list: odd, so lanes hit different banks */
+#define PROJ_CLAIM 4096          /* entries of a proposal table */
 
 __global__ __launch_bounds__(256) void k_proj_resolve(
     const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
     const int32_t* __restrict__ kp_idx, int n_inl, const float2* __restrict__ uv,
     const int32_t* __restrict__ point_ids, int R, const uint32_t* __restrict__ map_desc,
-    float radius, int max_hamming, const uint32_t* __restrict__ cand,
+    double gate_dd, int max_hamming, const uint32_t* __restrict__ cand,
     const int32_t* __restrict__ cand_n, int32_t* __restrict__ matched)
 {
     // One workgroup of four waves.  Wave 0 resolves the inliers in order, 64 at
@@ -1776,9 +1794,11 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
     extern __shared__ uint32_t plds[];
     const int BUF = PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK;
     int32_t* res = reinterpret_cast<int32_t*>(plds + 2 * BUF);
-    uint32_t* taken = plds + 2 * BUF + PROJ_CHUNK;
+    uint32_t* claims = plds + 2 * BUF + PROJ_CHUNK; // two proposal tables, one per chunk parity
+    uint32_t* taken = claims + 2 * PROJ_CLAIM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int w = tid; w < (R + 31) / 32; w += 256) taken[w] = 0;
+    for (int w = tid; w < 2 * PROJ_CLAIM; w += 256) claims[w] = 0;
 
     auto load_chunk = [&](int c0, int buf, int t0, int nt) {
         // threads t0 .. t0+nt-1 of the workgroup copy chunk c0 into buffer buf
@@ -1800,8 +1820,12 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
         const int nc = min(PROJ_CHUNK, n_inl - c0);
         if (wave != 0) {
             load_chunk(c0 + PROJ_CHUNK, buf ^ 1, 64, 192);
+            // and clear the proposal table the next chunk will use
+            for (int w = tid - 64; w < PROJ_CLAIM; w += 192) claims[(buf ^ 1) * PROJ_CLAIM + w] = 0;
         } else {
             const uint32_t* stage = plds + buf * BUF;
+            uint32_t* claim = claims + buf * PROJ_CLAIM;
+            uint32_t round = 0;
             const int32_t* stage_n = reinterpret_cast<const int32_t*>(stage + PROJ_CHUNK * PROJ_STRIDE);
             volatile uint32_t* vt = taken;
             // list header: number of stored candidates; bit 30: more passed the gates
@@ -1826,13 +1850,22 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
                     }
                     dry = prop < 0 && overflow; // the stored list ran out but more candidates exist
                 }
+                // Did an earlier open lane propose the same point?  Every proposal is
+                // entered in a hash table with atomicMax on (round, 63 - lane, point):
+                // the current round beats stale entries, the lowest lane wins its
+                // slot, and a lane that does not find its own entry stops.  Two
+                // different points in one slot stop the later lane needlessly, which
+                // only shortens this round's prefix.
+                ++round; // at most 64 rounds per chunk: each one finishes a lane
                 bool stop = dry;
-                if (__ballot(prop >= 0)) {
-#pragma unroll 7
-                    for (int d = 1; d < 64; ++d) {
-                        const int o = __shfl_up(prop, d);
-                        stop = stop || (lane >= d && prop >= 0 && o == prop);
-                    }
+                if (prop >= 0) {
+                    const uint32_t mine = (round << 26) | ((uint32_t)(63 - lane) << 20) | (uint32_t)prop;
+                    const uint32_t slot = ((uint32_t)prop * 2654435761u) >> 20; // 12 bits
+                    atomicMax(&claim[slot], mine);
+                    wave_lds_fence();
+                    stop = ((volatile uint32_t*)claim)[slot] != mine;
+                } else {
+                    wave_lds_fence();
                 }
                 const unsigned long long mstop = __ballot(stop && !done);
                 const int k = mstop ? __ffsll((long long)mstop) - 1 : 64;
@@ -1852,7 +1885,7 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
                         for (int j = lane; j < R; j += 64) {
                             if ((vt[j >> 5] >> (j & 31)) & 1u) continue;
                             float2 p = uv[j];
-                            if (!proj_gate(p.x, p.y, kx, ky, radius)) continue;
+                            if (!proj_gate(p.x, p.y, kx, ky, gate_dd)) continue;
                             int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
                             if (h <= max_hamming) best = min(best, ((uint32_t)h << 20) | (uint32_t)j);
                         }
@@ -2083,24 +2116,48 @@ int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int ns
     return 0;
 }
 
+// Largest double dd with (float)sqrt(dd) <= radius, or -1 if there is none: the
+// predicate is monotone in dd, so bisect over the bit patterns of the
+// non-negative doubles (their integer order is their numeric order).
+double slamfe_proj_gate_threshold(float radius)
+{
+    auto ok = [&](uint64_t bits) {
+        double dd;
+        __builtin_memcpy(&dd, &bits, sizeof dd);
+        return (float)sqrt(dd) <= radius;
+    };
+    if (!(radius >= 0.f) || !ok(0)) return -1.0; // negative or NaN radius: nothing passes
+    uint64_t lo = 0, hi = 0x7ff0000000000000ULL; // +infinity
+    if (ok(hi)) lo = hi;
+    while (hi - lo > 1) { // invariant: ok(lo), !ok(hi)
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (ok(mid)) lo = mid;
+        else hi = mid;
+    }
+    double dd;
+    __builtin_memcpy(&dd, &lo, sizeof dd);
+    return dd;
+}
+
 int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
                              const int32_t* kp_idx, int n_inl, const float* uv,
                              const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
                              int max_hamming, uint32_t* cand, int32_t* cand_n, int32_t* matched)
 {
     if (n_inl <= 0) return 0;
+    const double gate_dd = slamfe_proj_gate_threshold(radius);
     hipLaunchKernelGGL(k_proj_candidates, dim3(n_inl), dim3(256), 0, s, kps,
                        reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
                        reinterpret_cast<const float2*>(uv), point_ids, R,
-                       reinterpret_cast<const uint32_t*>(map_desc), radius, max_hamming, cand, cand_n);
+                       reinterpret_cast<const uint32_t*>(map_desc), gate_dd, max_hamming, cand, cand_n);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(256),
-                       (2 * (PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK) + PROJ_CHUNK) * 4 +
+                       (2 * (PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK) + PROJ_CHUNK + 2 * PROJ_CLAIM) * 4 +
                            ((size_t)R + 31) / 32 * 4 + 4,
                        s, kps,
                        reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
                        reinterpret_cast<const float2*>(uv), point_ids, R,
-                       reinterpret_cast<const uint32_t*>(map_desc), radius, max_hamming, cand, cand_n,
+                       reinterpret_cast<const uint32_t*>(map_desc), gate_dd, max_hamming, cand, cand_n,
                        matched);
     LAUNCH_CHECK();
     return 0;
@@ -2226,7 +2283,8 @@ int slamfe_kernels_init(size_t sort_lds_bytes)
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SLAMFE_PROJ_MAX_POINTS / 8 + (2 * (PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK) + PROJ_CHUNK) * 4 + 64);
+                            SLAMFE_PROJ_MAX_POINTS / 8 +
+                                (2 * (PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK) + PROJ_CHUNK + 2 * PROJ_CLAIM) * 4 + 64);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
