@@ -366,6 +366,35 @@ def test_reproject_then_search_on_device(fe_orb):
     assert np.array_equal(fe_orb.search_by_projection(f, kp_idx, want_uv, want_idx), want)
 
 
+@pytest.mark.parametrize("radius", [32.0, 31.7, 0.0, 1.0, 5.000001, 1e9, -1.0])
+def test_search_by_projection_radius_boundary(fe_orb, radius):
+    # points placed on and next to the circle of the given radius around their
+    # keypoint, identical descriptors: only the pixel gate (float differences,
+    # double squares, root narrowed to float, Init.cc:389-391) decides
+    img = synth.textured_canvas(640, 480, 53)
+    f = fe_orb.extract_keypoints(img)
+    n = 300
+    kp_idx = np.arange(n, dtype=np.int32)
+    xy = f.pt[:n]
+    r32 = np.float32(abs(radius) if abs(radius) < 1e6 else 32.0)
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    base = np.stack([np.cos(ang), np.sin(ang)], 1)
+    uv = (xy.astype(np.float64) + base * float(r32)).astype(np.float32)
+    # nudge a third of the points outwards and a third inwards by one float step
+    uv[0::3] = np.nextafter(uv[0::3], np.float32(1e9) * np.sign(base[0::3]).astype(np.float32))
+    uv[1::3] = np.nextafter(uv[1::3], xy[1::3])
+    uv[::7] = xy[::7] + np.array([r32, 0], np.float32)   # exactly on the axis at distance r
+    ids = np.arange(n, dtype=np.int32)
+    fe_orb.map_put(ids, f.descriptors[:n])
+    got = fe_orb.search_by_projection(f, kp_idx, uv, ids, radius=radius)
+    want = O.search_by_projection(f.pt, f.descriptors, kp_idx, uv, f.descriptors[:n], ids, radius=radius)
+    assert np.array_equal(got, want)
+    if radius in (32.0, 31.7, 1.0, 5.000001):
+        assert 0 < (got >= 0).sum()
+    if radius < 0:
+        assert (got == -1).all()
+
+
 def test_search_by_projection_no_points(fe_orb):
     img = synth.textured_canvas(200, 160, 52)
     f = fe_orb.extract_keypoints(img)
