@@ -185,6 +185,30 @@ def test_frame_handle_expires(fe_orb):
     assert e.value.code == abi.SLAMFE_E_HANDLE
 
 
+def test_extract_fuzz_parameters():
+    # seeded random frame sizes and ORB parameters (levels, scale factor, threshold,
+    # quota, border), both modes, against the checker
+    from slam_amd.frontend import FrontEnd
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for case in range(24):
+        w, h = int(rng.integers(72, 700)), int(rng.integers(72, 520))
+        kw = dict(mode=int(case % 3 == 2), fast_threshold=int(rng.integers(5, 60)),
+                  nfeatures=int(rng.integers(40, 3000)), nlevels=int(rng.integers(1, 9)),
+                  scale_factor=float(rng.choice([1.1, 1.2, 1.25, 1.5, 1.7])),
+                  edge_threshold=int(rng.integers(22, 40)))
+        img = synth.textured_canvas(w, h, 100 + case)
+        if case % 4 == 1:  # a BGR frame
+            img = np.ascontiguousarray(np.stack([img, np.roll(img, 1, 1), np.roll(img, 1, 0)], axis=2))
+        with FrontEnd(max_width=w, max_height=h, map_capacity=0, **kw) as fe:
+            f = fe.extract_keypoints(img)
+            kps, desc = O.extract(oracle_params(fe), img)
+            assert len(f) == len(kps), (case, w, h, kw, len(f), len(kps))
+            assert_frame_equal(f, kps, desc)
+            checked += len(kps)
+    assert checked > 5000
+
+
 # ------------------------------------------------------------------ matching
 @pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (1, 2), (257, 63), (64, 1000), (5, 0),
                                    (3001, 2999), (100, 20000),
