@@ -185,6 +185,33 @@ def test_frame_handle_expires(fe_orb):
     assert e.value.code == abi.SLAMFE_E_HANDLE
 
 
+@pytest.mark.parametrize("nframes", [8, 11, 19])
+def test_extract_and_match_large_batches(nframes):
+    # eight frames and more take the grid that keeps a frame's workgroups on one
+    # XCD (frame = blockIdx.z * 8 + blockIdx.x); 11 and 19 leave the last group ragged
+    import torch
+    from slam_amd.frontend import FrontEnd
+    frames = synth.frame_stream(320, 240, nframes, seed=21 + nframes)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=500, max_width=320, max_height=240,
+                  max_batch=nframes, frame_slots=2 * nframes, map_capacity=0) as fe:
+        got = fe.extract_batch(list(frames))
+        p = oracle_params(fe)
+        want = [O.extract(p, fr) for fr in frames]
+        for f, (kps, desc) in zip(got, want):
+            assert len(kps) > 300
+            assert_frame_equal(f, kps, desc)
+        cap = fe.max_keypoints
+        out = torch.zeros((nframes - 1, cap, 16), dtype=torch.uint8, device="cuda")
+        fe.match_resident_batch(got[1].handle, got[0].handle, nframes - 1, out.data_ptr())
+        fe.sync()
+        rows = out.cpu().numpy()
+        for i in range(nframes - 1):
+            m = np.frombuffer(rows[i].tobytes(), dtype=abi.MATCH2_DTYPE)[:len(got[i + 1])]
+            ref = O.match_knn2(want[i + 1][1], want[i][1])
+            for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+                assert np.array_equal(m[name], ref[name]), (i, name)
+
+
 def test_extract_fuzz_parameters():
     # seeded random frame sizes and ORB parameters (levels, scale factor, threshold,
     # quota, border), both modes, against the checker
