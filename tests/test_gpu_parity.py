@@ -212,6 +212,41 @@ def test_extract_and_match_large_batches(nframes):
                 assert np.array_equal(m[name], ref[name]), (i, name)
 
 
+@pytest.mark.parametrize("channels", [1, 3])
+def test_extract_resident_and_padded_rows(channels):
+    # frames already in device memory with padded rows and a gap between frames,
+    # and host frames with padded rows through the C ABI: the row stride is honoured
+    import ctypes as C
+    import torch
+    from slam_amd.frontend import FrontEnd
+    n, w, h = 9, 333, 201
+    gray = synth.frame_stream(w, h, n, seed=77)
+    frames = gray if channels == 1 else np.stack([gray, np.roll(gray, 2, 2), np.roll(gray, 1, 1)], axis=3)
+    row = w * channels
+    stride, fstride = row + 37, (row + 37) * h + 1000
+    buf = np.full(n * fstride, 0xAB, np.uint8)
+    for i in range(n):
+        view = buf[i * fstride:i * fstride + stride * h].reshape(h, stride)
+        view[:, :row] = frames[i].reshape(h, row)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=400, max_width=w, max_height=h,
+                  max_batch=n, frame_slots=2 * n, map_capacity=0) as fe:
+        p = oracle_params(fe)
+        want = [O.extract(p, np.ascontiguousarray(fr)) for fr in frames]
+        d = torch.from_numpy(buf).cuda()
+        hd = fe.extract_resident(d.data_ptr(), n, w, h, stride, fstride, channels)
+        for i in range(n):
+            assert_frame_equal(fe.frame_download(int(hd[i])), *want[i])
+        # host frame with padded rows
+        cap = fe.max_keypoints
+        kps = np.zeros(cap, abi.KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        cnt, handle = C.c_int32(), C.c_uint64()
+        rc = fe._lib.slamfe_extract(fe._ctx, buf[3 * fstride:].ctypes.data, w, h, stride, channels,
+                                    kps.ctypes.data, desc.ctypes.data, cap, C.byref(cnt), C.byref(handle))
+        assert rc == 0
+        assert np.array_equal(kps[:cnt.value], want[3][0]) and np.array_equal(desc[:cnt.value], want[3][1])
+
+
 def test_extract_fuzz_parameters():
     # seeded random frame sizes and ORB parameters (levels, scale factor, threshold,
     # quota, border), both modes, against the checker
