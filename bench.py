@@ -302,6 +302,38 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 rel = float(t.item())
             hamming["reloc_2000x1M_gcmps"] = round(NQ * NT * R / rel / 1e9, 2)
+            if multi:
+                # throughput with successive query sets pipelined: the all-gather of
+                # set i (on RCCL's stream) overlaps the match kernel of set i+1
+                keys2 = [keys, torch.empty_like(keys)]
+                gath2 = [gathered, torch.empty_like(gathered)]
+
+                def pipelined(count):
+                    works = [None, None]
+                    for it in range(count + 2):
+                        b = it & 1
+                        if works[b] is not None:
+                            works[b].wait()
+                            fe.merge_shard_keys(gath2[b].data_ptr(), world, NQ, out.data_ptr())
+                            works[b] = None
+                        if it < count:
+                            fe.match_shard_keys(dq.data_ptr(), NQ, shard.data_ptr(), hi - lo, lo,
+                                                keys2[b].data_ptr())
+                            works[b] = dist.all_gather_into_tensor(gath2[b], keys2[b], async_op=True)
+
+                with torch.cuda.stream(stream):
+                    pipelined(4)
+                    torch.cuda.synchronize(dev)
+                    dist.barrier()
+                    torch.cuda.synchronize(dev)
+                    p0 = time.perf_counter()
+                    pipelined(R)
+                    torch.cuda.synchronize(dev)
+                    dist.barrier()
+                    pl = time.perf_counter() - p0
+                t = torch.tensor([pl], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                hamming["reloc_pipelined_gcmps"] = round(NQ * NT * R / float(t.item()) / 1e9, 2)
             if world == 1 and not multi:
                 # the same job on the vector-ALU popcount kernel (v_xor + v_bcnt), against
                 # the measured integer-VALU ceiling: 16 lane-ops per comparison
