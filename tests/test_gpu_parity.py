@@ -320,6 +320,25 @@ def test_match_either_kernel_forced(kernel):
                 assert np.array_equal(got[name], want[name]), (kernel, nq, nt, name)
 
 
+def test_match_resident_frames_with_few_or_no_keypoints():
+    # the plan is made for the slot capacity, the kernels work from the counts on the
+    # device: frames with a handful of keypoints, and a flat frame with none
+    from slam_amd.frontend import FrontEnd
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=40, max_width=320, max_height=240,
+                  max_batch=3, map_capacity=0) as fe:
+        a = synth.textured_canvas(320, 240, 91)
+        b = synth.textured_canvas(320, 240, 92)
+        flat = np.full((240, 320), 100, np.uint8)
+        fa, fb, ff = fe.extract_batch([a, b, flat])
+        assert 0 < len(fa) < 128 and 0 < len(fb) < 128 and len(ff) == 0
+        for q, t in ((fa, fb), (fb, fa), (fa, ff), (ff, fa), (fa, fa)):
+            got = fe.knn_match_frames(q, t)
+            want = O.match_knn2(q.descriptors, t.descriptors)
+            assert len(got) == len(want)
+            for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+                assert np.array_equal(got[name], want[name]), name
+
+
 def test_match_empty_query(fe_orb):
     assert len(fe_orb.knn_match(np.zeros((0, 32), np.uint8), np.zeros((4, 32), np.uint8))) == 0
 
