@@ -249,6 +249,17 @@ int slamfe_search_by_projection_visible(slamfe_ctx* ctx, uint64_t frame_handle, 
                                         int n_inl, float radius, int max_hamming,
                                         int32_t* matched_point_id);
 
+/* Replaces the Init::triangulate calls of the per-match loop (Init.cc:260, with
+ * Init.cc:5-17) by one call for n point pairs: for pair i the 4x4 system of
+ * Init.cc:8-11 from P1, P2 (3x4, row-major float: Init.cc:168-176, 195) and the
+ * pixel positions pts1[2i..], pts2[2i..] (keypoints1[queryIdx].pt,
+ * keypoints2[trainIdx].pt), its singular value decomposition (Init.cc:14) and
+ * xyz[3i..] = Vt.row(3)[0..2] / Vt.row(3)[3] (Init.cc:15-16).  Results may be
+ * inf / nan, which the caller tests as at Init.cc:262.  The SVD is the one-sided
+ * Jacobi method OpenCV applies to small float matrices. */
+int slamfe_triangulate(slamfe_ctx* ctx, const float* P1, const float* P2, const float* pts1,
+                       const float* pts2, int n, float* xyz);
+
 /* Wait for everything queued on the context's stream (no counterpart in the
  * reference, whose OpenCV calls are synchronous). */
 int slamfe_sync(slamfe_ctx* ctx);

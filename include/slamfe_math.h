@@ -95,4 +95,108 @@ SLAMFE_HD void slamfe_sincos_deg(float angle_deg, float* s_out, float* c_out)
     *c_out = (float)c;
 }
 
+/* Row 3 of Vt of cv::SVD::compute(A, W, U, Vt, MODIFY_A | FULL_UV) for a 4x4
+ * float matrix, i.e. the right singular vector of the smallest singular value
+ * that Init::triangulate reads (Init.cc:14-15, 28-29).  OpenCV's small-matrix
+ * path is a one-sided Jacobi method on the columns of A (kept as rows of At):
+ * column norms and rotation parameters in double, matrix entries in float, at
+ * most 30 sweeps, threshold 2 * FLT_EPSILON, singular values sorted in
+ * descending order.  hypot(p, beta) is evaluated as sqrt(p*p + beta*beta) so
+ * that host and device round alike.  A[r*4 + c] row-major. */
+SLAMFE_HD void slamfe_svd4_last_row(const float* A, float* vt3)
+{
+    float At[4][4], Vt[4][4];
+    double W[4];
+    const double eps = 1.1920928955078125e-07 * 2; /* FLT_EPSILON * 2 */
+    for (int i = 0; i < 4; ++i) {
+        double sd = 0;
+        for (int k = 0; k < 4; ++k) {
+            At[i][k] = A[k * 4 + i];
+            Vt[i][k] = i == k ? 1.f : 0.f;
+            double t = (double)At[i][k];
+            sd += t * t;
+        }
+        W[i] = sd;
+    }
+    for (int iter = 0; iter < 30; ++iter) {
+        int changed = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i + 1; j < 4; ++j) {
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < 4; ++k) p += (double)At[i][k] * (double)At[j][k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                double c, s;
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < 4; ++k) {
+                    float t0 = (float)(c * (double)At[i][k] + s * (double)At[j][k]);
+                    float t1 = (float)(-s * (double)At[i][k] + c * (double)At[j][k]);
+                    At[i][k] = t0;
+                    At[j][k] = t1;
+                    a += (double)t0 * (double)t0;
+                    b += (double)t1 * (double)t1;
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = 1;
+                for (int k = 0; k < 4; ++k) {
+                    float t0 = (float)(c * (double)Vt[i][k] + s * (double)Vt[j][k]);
+                    float t1 = (float)(-s * (double)Vt[i][k] + c * (double)Vt[j][k]);
+                    Vt[i][k] = t0;
+                    Vt[j][k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < 4; ++i) {
+        double sd = 0;
+        for (int k = 0; k < 4; ++k) {
+            double t = (double)At[i][k];
+            sd += t * t;
+        }
+        W[i] = sqrt(sd);
+    }
+    /* descending selection sort of the singular values; the row that ends last */
+    int idx[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 3; ++i) {
+        int j = i;
+        for (int k = i + 1; k < 4; ++k)
+            if (W[idx[j]] < W[idx[k]]) j = k;
+        int t = idx[i];
+        idx[i] = idx[j];
+        idx[j] = t;
+    }
+    for (int k = 0; k < 4; ++k) vt3[k] = Vt[idx[3]][k];
+}
+
+/* Init::triangulate (Init.cc:5-31): the 4x4 system of one point pair and its
+ * solution.  P1, P2: 3x4 projection matrices, row-major float.  Rows of A are
+ * x * P.row(2) - P.row(0) and y * P.row(2) - P.row(1) in float; the result is
+ * Vt.row(3)[0..2] scaled by the float value of 1.0 / Vt.row(3)[3] (Init.cc:16). */
+SLAMFE_HD void slamfe_triangulate_point(const float* P1, const float* P2, float x1, float y1, float x2,
+                                        float y2, float* xyz)
+{
+    float A[16], v[4];
+    for (int k = 0; k < 4; ++k) {
+        A[k] = x1 * P1[8 + k] - P1[k];
+        A[4 + k] = y1 * P1[8 + k] - P1[4 + k];
+        A[8 + k] = x2 * P2[8 + k] - P2[k];
+        A[12 + k] = y2 * P2[8 + k] - P2[4 + k];
+    }
+    slamfe_svd4_last_row(A, v);
+    const float sc = (float)(1.0 / (double)v[3]);
+    xyz[0] = v[0] * sc;
+    xyz[1] = v[1] * sc;
+    xyz[2] = v[2] * sc;
+}
+
 #endif /* SLAMFE_MATH_H */

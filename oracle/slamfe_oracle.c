@@ -725,3 +725,17 @@ int orc_reproject(const float* pose, const float* K, const float* xyz, int npoin
     }
     return n;
 }
+
+
+/* Init::triangulate (Init.cc:5-31) for n point pairs.  The arithmetic is the
+ * shared float contract of slamfe_math.h (as for fastAtan2 and cos/sin): the
+ * one-sided Jacobi SVD OpenCV uses for small float matrices. */
+void orc_triangulate(const float* P1, const float* P2, const float* pts1, const float* pts2, int n,
+                     float* xyz)
+{
+    for (int i = 0; i < n; ++i)
+        slamfe_triangulate_point(P1, P2, pts1[2 * i], pts1[2 * i + 1], pts2[2 * i], pts2[2 * i + 1],
+                                 xyz + 3 * (size_t)i);
+}
+
+void orc_svd4_last_row(const float* A, float* vt3) { slamfe_svd4_last_row(A, vt3); }

@@ -118,6 +118,13 @@ void orc_matmul4x4(const float* a, const float* b, float* d);
 int orc_reproject(const float* pose, const float* K, const float* xyz, int npoints, float th, float W,
                   float H, float* uv, int32_t* idx);
 
+/* Init::triangulate (Init.cc:5-31) for n point pairs: P1, P2 3x4 row-major
+ * float, pts 2 floats per point, xyz 3 floats per pair (may be inf / nan, which
+ * Init.cc:262 tests).  orc_svd4_last_row: row 3 of Vt of the 4x4 SVD. */
+void orc_triangulate(const float* P1, const float* P2, const float* pts1, const float* pts2, int n,
+                     float* xyz);
+void orc_svd4_last_row(const float* A, float* vt3);
+
 #ifdef __cplusplus
 }
 #endif

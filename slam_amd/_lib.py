@@ -44,6 +44,7 @@ SIGNATURES = {
     "slamfe_map_put_xyz": (C.c_int, [ctxp, vp, vp, C.c_int]),
     "slamfe_reproject": (C.c_int, [ctxp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp,
                                    C.c_int, i32p]),
+    "slamfe_triangulate": (C.c_int, [ctxp, vp, vp, vp, vp, C.c_int, vp]),
     "slamfe_search_by_projection_visible": (C.c_int, [ctxp, C.c_uint64, vp, C.c_int, C.c_float, C.c_int,
                                                       vp]),
     "slamfe_search_by_projection": (C.c_int, [ctxp, C.c_uint64, vp, C.c_int, vp, vp, C.c_int,

@@ -86,6 +86,7 @@ struct slamfe_ctx {
     // set the last slamfe_reproject call left on the device
     float* map_xyz = nullptr;
     Scratch rp_uv_all, rp_mask, rp_off, rp_total, vis_uv, vis_idx;
+    Scratch tri_in, tri_out;
     int vis_count = -1;
 };
 
@@ -423,7 +424,7 @@ void slamfe_destroy(slamfe_ctx* c)
                     c->match_q.p, c->match_t.p, c->match_o.p, c->pj_idx.p, c->pj_uv.p,
                     c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p, c->ing_taps.p,
                     c->ing_bgr.p, c->map_xyz, c->rp_uv_all.p, c->rp_mask.p, c->rp_off.p, c->rp_total.p,
-                    c->vis_uv.p, c->vis_idx.p};
+                    c->vis_uv.p, c->vis_idx.p, c->tri_in.p, c->tri_out.p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -1039,6 +1040,31 @@ int slamfe_reproject(slamfe_ctx* c, const float* pose, const float* K, float th,
     HIPCHK(c, hipStreamSynchronize(s));
     if (uv) memcpy(uv, c->h_pin, (size_t)R * 8);
     if (point_idx) memcpy(point_idx, c->h_pin + (size_t)R * 8, (size_t)R * 4);
+    return SLAMFE_OK;
+}
+
+int slamfe_triangulate(slamfe_ctx* c, const float* P1, const float* P2, const float* pts1,
+                       const float* pts2, int n, float* xyz)
+{
+    if (!c || !P1 || !P2 || n < 0 || (n > 0 && (!pts1 || !pts2 || !xyz))) return SLAMFE_E_INVALID;
+    if (n == 0) return SLAMFE_OK;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    int rc;
+    const size_t pb = (size_t)n * 8, ob = (size_t)n * 12;
+    if ((rc = grow(c, c->tri_in, 2 * pb))) return rc;
+    if ((rc = grow(c, c->tri_out, ob))) return rc;
+    if ((rc = pin_reserve(c, 2 * pb + ob))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipStreamSynchronize(s));
+    memcpy(c->h_pin, pts1, pb);
+    memcpy(c->h_pin + pb, pts2, pb);
+    HIPCHK(c, hipMemcpyAsync(c->tri_in.p, c->h_pin, 2 * pb, hipMemcpyHostToDevice, s));
+    KCHK(c, slamfe_launch_triangulate(s, P1, P2, (const float*)c->tri_in.p,
+                                      (const float*)((const uint8_t*)c->tri_in.p + pb), n,
+                                      (float*)c->tri_out.p));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + 2 * pb, c->tri_out.p, ob, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    memcpy(xyz, c->h_pin + 2 * pb, ob);
     return SLAMFE_OK;
 }
 

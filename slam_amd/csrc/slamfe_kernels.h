@@ -55,6 +55,8 @@ int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const ui
 int slamfe_launch_reproject(hipStream_t s, const float* xyz, int npoints, const float* M16, float th,
                             float W, float H, float* uv_all, uint64_t* wave_mask, int32_t* wave_off,
                             int32_t* total, float* vis_uv, int32_t* vis_idx);
+int slamfe_launch_triangulate(hipStream_t s, const float* P1, const float* P2, const float* d_pts1,
+                              const float* d_pts2, int n, float* d_xyz);
 int slamfe_kernels_init(size_t sort_lds_bytes);
 
 #endif

@@ -2273,6 +2273,43 @@ int slamfe_launch_reproject(hipStream_t s, const float* xyz, int npoints, const 
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Triangulation of point pairs, Init::triangulate (Init.cc:5-31): one lane per
+// pair builds the 4x4 system and runs the one-sided Jacobi SVD of
+// slamfe_math.h (the same source the host side compiles).
+// ---------------------------------------------------------------------------
+struct slamfe_proj_pair { float p1[12], p2[12]; };
+
+__global__ __launch_bounds__(64) void k_triangulate(slamfe_proj_pair P, const float2* __restrict__ pts1,
+                                                    const float2* __restrict__ pts2, int n,
+                                                    float* __restrict__ xyz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float2 a = pts1[i], b = pts2[i];
+    float out[3];
+    slamfe_triangulate_point(P.p1, P.p2, a.x, a.y, b.x, b.y, out);
+    xyz[3 * (size_t)i] = out[0];
+    xyz[3 * (size_t)i + 1] = out[1];
+    xyz[3 * (size_t)i + 2] = out[2];
+}
+
+int slamfe_launch_triangulate(hipStream_t s, const float* P1, const float* P2, const float* d_pts1,
+                              const float* d_pts2, int n, float* d_xyz)
+{
+    if (n <= 0) return 0;
+    slamfe_proj_pair P;
+    for (int i = 0; i < 12; ++i) {
+        P.p1[i] = P1[i];
+        P.p2[i] = P2[i];
+    }
+    hipLaunchKernelGGL(k_triangulate, dim3((n + 63) / 64), dim3(64), 0, s, P,
+                       reinterpret_cast<const float2*>(d_pts1), reinterpret_cast<const float2*>(d_pts2), n,
+                       d_xyz);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // Raise the dynamic-LDS limits of the two kernels that may need more than the
 // default 64 KiB (4K-wide frames; very large local maps).
 int slamfe_kernels_init(size_t sort_lds_bytes)

@@ -282,6 +282,19 @@ class FrontEnd:
             C.c_float(radius), max_hamming, out.ctypes.data))
         return out[:len(kp_idx)]
 
+    def triangulate(self, P1, P2, pts1, pts2) -> np.ndarray:
+        """``Init::triangulate`` (Init.cc:5-31) for point pairs: [n, 3] float32."""
+        P1 = np.ascontiguousarray(P1, np.float32).reshape(3, 4)
+        P2 = np.ascontiguousarray(P2, np.float32).reshape(3, 4)
+        a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+        if len(a) != len(b):
+            raise ValueError("one point of each view per pair")
+        out = np.zeros((max(len(a), 1), 3), np.float32)
+        self._check(self._lib.slamfe_triangulate(self._ctx, P1.ctypes.data, P2.ctypes.data, a.ctypes.data,
+                                                 b.ctypes.data, len(a), out.ctypes.data))
+        return out[:len(a)]
+
     def debug_read_level(self, frame_in_batch: int, level: int, blurred: bool) -> np.ndarray:
         """Test hook: a pyramid level of the most recent extraction."""
         cap = self.params.max_width * self.params.max_height

@@ -200,6 +200,18 @@ public:
         return hit;
     }
 
+    // Init::triangulate (Init.cc:5-31) for all the pairs of the per-match loop at
+    // once (Init.cc:260): P1, P2 3x4 row-major float, pts 2 floats per point;
+    // xyz gets 3 floats per pair (test them with std::isfinite as Init.cc:262 does).
+    void triangulate(const float* P1, const float* P2, const std::vector<float>& pts1,
+                     const std::vector<float>& pts2, std::vector<float>& xyz)
+    {
+        if (pts1.size() != pts2.size() || pts1.size() % 2) throw Error(SLAMFE_E_INVALID, "two floats per point, one point of each view per pair");
+        const int n = (int)(pts1.size() / 2);
+        xyz.resize((size_t)n * 3);
+        check(slamfe_triangulate(ctx_, P1, P2, pts1.data(), pts2.data(), n, xyz.data()));
+    }
+
     // matcher->knnMatch(descriptors1, descriptors2, matches, 2), Init.cc:131:
     // matches[i] holds up to k = 2 DMatch in (distance, trainIdx) order.
     void knnMatch(const Mat8& query, const Mat8& train, std::vector<std::vector<DMatch>>& matches, int k = 2)

@@ -211,3 +211,29 @@ def camera_scene(npoints: int, w: int, h: int, seed: int = 7):
     world = (pose.astype(np.float64) @ cam.T).T[:, :3]
     th = float(pose[2, 3])
     return pose, K, world.astype(np.float32), th
+
+
+def two_view_scene(npoints: int, w: int, h: int, seed: int = 9):
+    """Two camera projection matrices as Init.cc:168-195 builds them (P1 = K[I|0],
+    P2 = K[R|t], f = 984) and the pixel positions of npoints scene points in both
+    views, with up to half a pixel of noise; a few pairs are degenerate (the same
+    pixel in both views).  Returns (P1 3x4 f32, P2 3x4 f32, pts1 [n,2] f32, pts2)."""
+    idx = np.arange(npoints, dtype=np.uint64)
+
+    def uni(stream):
+        return (hash_u64(seed, stream, idx) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+    K = np.array([[984.0, 0, w / 2.0], [0, 984.0, h / 2.0], [0, 0, 1]])
+    ang = 0.05
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([[-0.1], [0.01], [0.02]])
+    P1 = (K @ np.hstack([np.eye(3), np.zeros((3, 1))])).astype(np.float32)
+    P2 = (K @ np.hstack([R, t])).astype(np.float32)
+    z = 1.0 + 30.0 * uni(1)
+    X = np.stack([(uni(2) - 0.5) * z * 0.6, (uni(3) - 0.5) * z * 0.45, z, np.ones(npoints)], 0)
+    a = P1.astype(np.float64) @ X
+    b = P2.astype(np.float64) @ X
+    pts1 = (a[:2] / a[2]).T + (np.stack([uni(4), uni(5)], 1) - 0.5)
+    pts2 = (b[:2] / b[2]).T + (np.stack([uni(6), uni(7)], 1) - 0.5)
+    pts2[::37] = pts1[::37]
+    return P1, P2, pts1.astype(np.float32), pts2.astype(np.float32)

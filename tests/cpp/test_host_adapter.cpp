@@ -161,8 +161,24 @@ int main(int argc, char** argv)
         REQUIRE((int)keypoints3.size() == n3 && n3 > 100);
         REQUIRE(std::memcmp(keypoints3.data(), k1.data(), (size_t)n3 * sizeof(slamfe_keypoint)) == 0);
         REQUIRE(std::memcmp(descriptors3.data.data(), d1.data(), (size_t)n3 * 32) == 0);
-        std::printf("host adapter ok: %d/%d keypoints, %d good matches, %d map hits, %d reprojected, %d keypoints after resize\n",
-                    n1, n2, oracle_good, hits, R, n3);
+
+        // Init::triangulate for all good matches at once (Init.cc:260, 5-17)
+        const float P1[12] = {f, 0, W / 2.0f, 0, 0, f, H / 2.0f, 0, 0, 0, 1, 0};
+        const float P2[12] = {f, 0, W / 2.0f, -98.4f, 0, f, H / 2.0f, 9.84f, 0, 0, 1, 0.02f};
+        std::vector<float> t1, t2, txyz, oxyz;
+        for (auto& m : goodMatches) {
+            t1.push_back(keypoints1[(size_t)m.queryIdx].pt.x);
+            t1.push_back(keypoints1[(size_t)m.queryIdx].pt.y);
+            t2.push_back(keypoints2[(size_t)m.trainIdx].pt.x);
+            t2.push_back(keypoints2[(size_t)m.trainIdx].pt.y);
+        }
+        fe.triangulate(P1, P2, t1, t2, txyz);
+        oxyz.resize(txyz.size());
+        orc_triangulate(P1, P2, t1.data(), t2.data(), (int)goodMatches.size(), oxyz.data());
+        REQUIRE(txyz.size() == goodMatches.size() * 3);
+        REQUIRE(std::memcmp(txyz.data(), oxyz.data(), txyz.size() * sizeof(float)) == 0);
+        std::printf("host adapter ok: %d/%d keypoints, %d good matches, %d map hits, %d reprojected, %d keypoints after resize, %d triangulated\n",
+                    n1, n2, oracle_good, hits, R, n3, (int)goodMatches.size());
     } catch (const slamfe::Error& e) {
         std::fprintf(stderr, "slamfe::Error %d: %s\n", e.code, e.what());
         return 3;

@@ -231,3 +231,21 @@ def reproject(pose, K, xyz, th, W, H):
     r = lib().orc_reproject(_p(pose), _p(K), _p(xyz), n, C.c_float(th), C.c_float(W), C.c_float(H),
                             _p(uv), _p(idx))
     return uv[:r].copy(), idx[:r].copy()
+
+
+def triangulate(P1, P2, pts1, pts2):
+    P1 = np.ascontiguousarray(P1, np.float32).reshape(3, 4)
+    P2 = np.ascontiguousarray(P2, np.float32).reshape(3, 4)
+    pts1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = len(pts1)
+    out = np.zeros((max(n, 1), 3), np.float32)
+    lib().orc_triangulate(_p(P1), _p(P2), _p(pts1), _p(pts2), n, _p(out))
+    return out[:n]
+
+
+def svd4_last_row(A):
+    A = np.ascontiguousarray(A, np.float32).reshape(4, 4)
+    out = np.zeros(4, np.float32)
+    lib().orc_svd4_last_row(_p(A), _p(out))
+    return out

@@ -293,3 +293,80 @@ def reproject(pose, K, xyz, th, W, H):
         uv.append((pt[0], pt[1]))
         idx.append(i)
     return np.array(uv, np.float32).reshape(-1, 2), np.array(idx, np.int32)
+
+
+def svd4_last_row(A):
+    """One-sided Jacobi on the columns of a 4x4 float32 matrix (norms and rotation
+    parameters in float64, entries in float32, <= 30 sweeps, threshold
+    2*FLT_EPSILON); returns the row of Vt that belongs to the smallest singular
+    value after a descending selection sort (cv::SVD::compute, Init.cc:14-15)."""
+    f32, f64 = np.float32, np.float64
+    At = [[f32(A[k][i]) for k in range(4)] for i in range(4)]
+    Vt = [[f32(1) if i == k else f32(0) for k in range(4)] for i in range(4)]
+    W = []
+    for i in range(4):
+        sd = f64(0)
+        for k in range(4):
+            sd = sd + f64(At[i][k]) * f64(At[i][k])
+        W.append(sd)
+    eps = f64(np.finfo(np.float32).eps) * 2
+    for _ in range(30):
+        changed = False
+        for i in range(3):
+            for j in range(i + 1, 4):
+                a, b, p = W[i], W[j], f64(0)
+                for k in range(4):
+                    p = p + f64(At[i][k]) * f64(At[j][k])
+                if abs(p) <= eps * np.sqrt(a * b):
+                    continue
+                p = p * 2
+                beta = a - b
+                gamma = np.sqrt(p * p + beta * beta)
+                if beta < 0:
+                    delta = (gamma - beta) * 0.5
+                    s_ = np.sqrt(delta / gamma)
+                    c_ = p / (gamma * s_ * 2)
+                else:
+                    c_ = np.sqrt((gamma + beta) / (gamma * 2))
+                    s_ = p / (gamma * c_ * 2)
+                a = b = f64(0)
+                for M in (At, Vt):
+                    for k in range(4):
+                        t0 = f32(c_ * f64(M[i][k]) + s_ * f64(M[j][k]))
+                        t1 = f32(-s_ * f64(M[i][k]) + c_ * f64(M[j][k]))
+                        M[i][k], M[j][k] = t0, t1
+                        if M is At:
+                            a = a + f64(t0) * f64(t0)
+                            b = b + f64(t1) * f64(t1)
+                W[i], W[j] = a, b
+                changed = True
+        if not changed:
+            break
+    for i in range(4):
+        sd = f64(0)
+        for k in range(4):
+            sd = sd + f64(At[i][k]) * f64(At[i][k])
+        W[i] = np.sqrt(sd)
+    idx = [0, 1, 2, 3]
+    for i in range(3):
+        j = i
+        for k in range(i + 1, 4):
+            if W[idx[j]] < W[idx[k]]:
+                j = k
+        idx[i], idx[j] = idx[j], idx[i]
+    return np.array(Vt[idx[3]], np.float32)
+
+
+def triangulate(P1, P2, pts1, pts2):
+    """Init::triangulate (Init.cc:5-31) for point pairs, written out literally."""
+    f32 = np.float32
+    P1 = np.asarray(P1, np.float32).reshape(3, 4)
+    P2 = np.asarray(P2, np.float32).reshape(3, 4)
+    out = []
+    with np.errstate(all="ignore"):
+        for (x1, y1), (x2, y2) in zip(np.asarray(pts1, np.float32), np.asarray(pts2, np.float32)):
+            A = np.stack([f32(x1) * P1[2] - P1[0], f32(y1) * P1[2] - P1[1],
+                          f32(x2) * P2[2] - P2[0], f32(y2) * P2[2] - P2[1]]).astype(np.float32)
+            v = svd4_last_row(A)
+            out.append(v[:3] * f32(1.0 / float(v[3])))
+    return np.array(out, np.float32).reshape(-1, 3)

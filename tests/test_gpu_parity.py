@@ -500,6 +500,18 @@ def test_search_by_projection_radius_boundary(fe_orb, radius):
         assert (got == -1).all()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 3000])
+def test_triangulate_point_pairs(fe_orb, n):
+    # Init.cc:260 with Init.cc:5-17 for all pairs at once; the float contract is one
+    # source compiled for host and device, so the bits agree
+    P1, P2, p1, p2 = synth.two_view_scene(n, 640, 480, 30 + n)
+    got = fe_orb.triangulate(P1, P2, p1, p2)
+    want = O.triangulate(P1, P2, p1, p2)
+    assert got.shape == (n, 3)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert len(fe_orb.triangulate(P1, P2, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32))) == 0
+
+
 def test_search_by_projection_no_points(fe_orb):
     img = synth.textured_canvas(200, 160, 52)
     f = fe_orb.extract_keypoints(img)

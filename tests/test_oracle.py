@@ -394,6 +394,38 @@ def test_reproject_gates():
     assert np.allclose(uv[2], [99, 79])
 
 
+def test_svd4_last_row_against_numpy_and_slow_definition():
+    rng = np.random.default_rng(17)
+    for _ in range(60):
+        A = rng.normal(size=(4, 4)).astype(np.float32)
+        v = O.svd4_last_row(A)
+        assert np.array_equal(v.view(np.uint32), S.svd4_last_row(A).view(np.uint32))
+        u, sv, vt = np.linalg.svd(A.astype(np.float64))
+        r = vt[3] if np.dot(vt[3], v) >= 0 else -vt[3]
+        gap = (sv[2] - sv[3]) / sv[0]
+        assert np.abs(r - v).max() < 2e-5 / max(gap, 1e-3), (gap, r, v)
+        assert abs(np.linalg.norm(v) - 1) < 1e-5
+    # a matrix with an exact null vector
+    A = np.array([[1, 0, 0, 0], [0, 2, 0, 0], [0, 0, 3, 0], [0, 0, 0, 0]], np.float32)
+    assert np.array_equal(np.abs(O.svd4_last_row(A)), [0, 0, 0, 1])
+
+
+def test_triangulate_recovers_scene_points_and_matches_slow_definition():
+    P1, P2, p1, p2 = synth.two_view_scene(240, 640, 480, 9)
+    got = O.triangulate(P1, P2, p1, p2)
+    want = S.triangulate(P1, P2, p1, p2)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # noise-free pixels of known points come back to float accuracy
+    X = np.array([[0.3, -0.2, 4.0, 1], [-1.0, 0.5, 9.0, 1], [2.0, 1.0, 25.0, 1]]).T
+    a = P1.astype(np.float64) @ X
+    b = P2.astype(np.float64) @ X
+    rec = O.triangulate(P1, P2, (a[:2] / a[2]).T, (b[:2] / b[2]).T)
+    assert np.abs(rec - X[:3].T).max() / 25.0 < 2e-3
+    # the same pixel in both views: the ray intersection is at the camera centres'
+    # line; whatever comes out, it must come out the same from both definitions
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+
+
 def test_search_by_projection_matches_literal_loop():
     xy, fd, inl, uv, pd, ids = _projection_case()
     got = O.search_by_projection(xy, fd, inl, uv, pd, ids)
