@@ -1,0 +1,298 @@
+// slamfe_k_describe.hip -- orientation, keypoint records, rBRIEF-256
+#include "slamfe_device.h"
+
+__device__ __constant__ int8_t c_pattern[1024] = SLAMFE_PATTERN_INIT;
+
+// ---------------------------------------------------------------------------
+// K5  orientation by intensity centroid (ICAngles inside cv::ORB).
+//
+// k_orient: a wavefront sums the moments of a keypoint's 749-pixel disc.
+// k_finish: one lane per keypoint turns the moments into the angle
+// (fastAtan2), its cos/sin for the descriptor, and the cv::KeyPoint record.
+// ---------------------------------------------------------------------------
+
+// A wavefront walks keypoints idx = wave, wave + nwaves, ...  The disc's 31 rows
+// of 31 bytes (starting at cx-15) are cut into 8 dwords each, 248 (row, dword)
+// tasks = 4 per lane.  Which bytes of a task lie inside the disc, their
+// x-offsets u and the row offset v depend on the lane only, so they are turned
+// once per wave into byte weights for v_dot4_u32_u8:
+//   T += dot4(x, inside ? u + 32 : 0)   S += dot4(x, inside ? 1 : 0)
+//   V += dot4(x, inside ? v + 16 : 0)   m10 = T - 32 S,  m01 = V - 16 S
+// leaving three dot products per loaded dword for every keypoint.
+__global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
+                                                int slot_base, int nslots,
+                                                const uint32_t* __restrict__ kp_key,
+                                                const uint32_t* __restrict__ kp_level,
+                                                const int32_t* __restrict__ kp_count,
+                                                int2* __restrict__ kp_mom, int max_kp, int nframes)
+{
+    const int f = wg_frame();
+    if (f >= nframes) return;
+    const int slot = (slot_base + f) % nslots;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform values are made scalar explicitly so that the per-keypoint reads
+    // below (key, level, level geometry) become scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(wg_item() * 4 + (int)(threadIdx.x >> 6));
+    const int nwaves = (int)gridDim.y * 4;
+    int n = kp_count[slot];
+    if (n > max_kp) n = max_kp;
+    if (wave >= n) return;
+    // half-widths of the disc rows |v| = 0..15, one nibble each
+    const unsigned long long umax = 0x3689abcddeeeffffULL;
+    uint32_t wT[4], wV[4], wS[4];
+    int trow[4], tcol[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int t = it * 64 + lane, row = t >> 3, dw = t & 7;
+        const int v = row - 15, av = v < 0 ? -v : v;
+        const int d = row < 31 ? (int)((umax >> (4 * av)) & 15ULL) : -1;
+        uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * dw + k - 15;
+            if (u >= -d && u <= d) {
+                a |= (uint32_t)(u + 32) << (8 * k);
+                b |= (uint32_t)(v + 16) << (8 * k);
+                c |= 1u << (8 * k);
+            }
+        }
+        wT[it] = a;
+        wV[it] = b;
+        wS[it] = c;
+        trow[it] = row < 31 ? row : 0;
+        tcol[it] = 4 * dw;
+    }
+    const uint8_t* frame = pyr + (size_t)f * g.frame_bytes;
+    const uint32_t* keys = kp_key + (size_t)slot * max_kp;
+    const uint32_t* levels = kp_level + (size_t)slot * max_kp;
+    uint32_t next_key = keys[wave], next_level = levels[wave];
+    for (int idx = wave; idx < n; idx += nwaves) { // uniform per wave
+        const uint32_t key = next_key;
+        const int l = (int)next_level;
+        if (idx + nwaves < n) { // fetched while this keypoint is processed
+            next_key = keys[idx + nwaves];
+            next_level = levels[idx + nwaves];
+        }
+        if (l < 0 || l >= g.nlevels) continue; // never true for entries written by k_select_write
+        const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
+        const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+        if (cx < 16 || cy < 16 || cx >= w - 17 || cy >= h - 16) continue; // reads must stay inside
+        const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 15) * pitch + (cx - 15);
+        uint32_t T = 0, V = 0, S = 0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            uint32_t x = 0;
+            if (it < 3 || lane < 56) x = load_u32_unaligned(base + trow[it] * pitch + tcol[it]);
+            T = __builtin_amdgcn_udot4(x, wT[it], T, false);
+            V = __builtin_amdgcn_udot4(x, wV[it], V, false);
+            S = __builtin_amdgcn_udot4(x, wS[it], S, false);
+        }
+        const int m10 = wave_sum((int)T - 32 * (int)S);
+        const int m01 = wave_sum((int)V - 16 * (int)S);
+        if (lane == 0) kp_mom[(size_t)slot * max_kp + idx] = make_int2(m10, m01);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base, int nslots,
+                                                const uint32_t* __restrict__ kp_key,
+                                                const uint32_t* __restrict__ kp_level,
+                                                const int32_t* __restrict__ kp_count,
+                                                const int2* __restrict__ kp_mom,
+                                                slamfe_keypoint* __restrict__ kps,
+                                                float2* __restrict__ kp_rot, int max_kp, int mode,
+                                                int patch_size, int nframes)
+{
+    const int f = wg_frame();
+    if (f >= nframes) return;
+    const int slot = (slot_base + f) % nslots;
+    const int idx = wg_item() * 256 + threadIdx.x;
+    int n = kp_count[slot];
+    if (n > max_kp) n = max_kp;
+    if (idx >= n) return;
+    const size_t e = (size_t)slot * max_kp + idx;
+    const uint32_t key = kp_key[e];
+    int l = (int)kp_level[e];
+    if (l < 0 || l >= g.nlevels) l = 0;
+    const float scale = g.lv[l].scale;
+    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+    slamfe_keypoint k;
+    if (mode == SLAMFE_MODE_ORB) {
+        int2 m = kp_mom[e];
+        k.angle = slamfe_fast_atan2((float)m.y, (float)m.x);
+        k.x = (float)cx * scale;
+        k.y = (float)cy * scale;
+        k.size = (float)patch_size * scale;
+        k.octave = l;
+    } else {
+        k.angle = -1.f;
+        k.x = (float)cx;
+        k.y = (float)cy;
+        k.size = 7.f;
+        k.octave = 0;
+    }
+    k.response = (float)SLAMFE_KEY_S(key);
+    k.class_id = -1;
+    kps[e] = k;
+    float sn, cs;
+    slamfe_sincos_deg(k.angle, &sn, &cs);
+    kp_rot[e] = make_float2(cs, sn);
+}
+
+// ---------------------------------------------------------------------------
+// K7  rBRIEF-256 (computeOrbDescriptors inside cv::ORB, reached from
+//     desc->compute, Init.cc:78).  Lane i of a wavefront evaluates tests i,
+//     64+i, 128+i, 192+i, so each wave ballot is 8 descriptor bytes.
+// ---------------------------------------------------------------------------
+#define DP_ROWS 37 /* samples reach +-18 px (|pattern| <= 13 * sqrt 2 = 18.4) */
+#define DP_DW 10   /* 37 bytes from column cx-18, read as 10 dwords */
+
+// A wavefront walks keypoints idx = wave, wave + nwaves, ...  For each one it
+// stages the 37-row neighbourhood (rows of 40 bytes starting at cx-18,
+// unaligned dword loads) in its own LDS slice and gathers the 512 samples from
+// there.  Per-lane constants (the lane's four tests as floats, its staging
+// tasks) are set up once per wave.  The rotation is evaluated on float pairs
+// (x, y) = P * (a, b) + Q * (-b, a): the same products and one sum per
+// coordinate as the scalar expressions x = px*a - py*b, y = px*b + py*a, so the
+// bits are identical.  Rounding to the nearest integer (ties to even, as
+// cvRound) is the addition of 1.5 * 2^23, which leaves the integer in the low
+// mantissa bits.
+__global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8_t* __restrict__ blur,
+                                                  int slot_base, int nslots,
+                                                  const uint32_t* __restrict__ kp_key,
+                                                  const uint32_t* __restrict__ kp_level,
+                                                  const int32_t* __restrict__ kp_count,
+                                                  const float2* __restrict__ kp_rot,
+                                                  uint8_t* __restrict__ desc, int max_kp, int nframes)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    __shared__ uint32_t patch32[4][DP_ROWS * DP_DW];
+    const int f = wg_frame();
+    if (f >= nframes) return;
+    const int slot = (slot_base + f) % nslots;
+    const int wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(wg_item() * 4 + wv);
+    const int nwaves = (int)gridDim.y * 4;
+    int n = kp_count[slot];
+    if (n > max_kp) n = max_kp;
+    if (wave >= n) return;
+    v2f P[4][2], Q[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int8_t* t = c_pattern + (j * 64 + lane) * 4;
+        P[j][0] = (v2f){(float)t[0], (float)t[0]};
+        Q[j][0] = (v2f){(float)t[1], (float)t[1]};
+        P[j][1] = (v2f){(float)t[2], (float)t[2]};
+        Q[j][1] = (v2f){(float)t[3], (float)t[3]};
+    }
+    constexpr int NIT = (DP_ROWS * DP_DW + 63) / 64;
+    int trow[NIT], tcol[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int t = it * 64 + lane, row = t / DP_DW;
+        trow[it] = row < DP_ROWS ? row : 0;
+        tcol[it] = 4 * (t - row * DP_DW);
+    }
+    uint32_t* my = patch32[wv];
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * (DP_DW * 4) + 18;
+    const uint8_t* frame = blur + (size_t)f * g.frame_bytes;
+    const uint32_t* keys = kp_key + (size_t)slot * max_kp;
+    const uint32_t* levels = kp_level + (size_t)slot * max_kp;
+    const float2* rots = kp_rot + (size_t)slot * max_kp;
+    uint32_t next_key = keys[wave], next_level = levels[wave];
+    float2 next_rot = rots[wave];
+    for (int idx = wave; idx < n; idx += nwaves) { // uniform per wave
+        const uint32_t key = next_key;
+        const int l = (int)next_level;
+        const float2 rot = next_rot; // cos, sin of the keypoint angle
+        if (idx + nwaves < n) {      // fetched while this keypoint is processed
+            next_key = keys[idx + nwaves];
+            next_level = levels[idx + nwaves];
+            next_rot = rots[idx + nwaves];
+        }
+        if (l < 0 || l >= g.nlevels) continue; // never true for entries written by k_select_write
+        const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
+        const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+        if (cx < 18 || cy < 18 || cx >= w - 22 || cy >= h - 18) continue; // reads must stay inside
+        const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 18) * pitch + (cx - 18);
+        uint32_t r[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            r[it] = 0;
+            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_DW)
+                r[it] = load_u32_unaligned(base + trow[it] * pitch + tcol[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_DW) my[it * 64 + lane] = r[it];
+        // only this wavefront reads what it wrote: LDS operations of one wave are
+        // ordered, the fences keep the compiler from moving accesses across
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
+        const v2f magic = {12582912.f, 12582912.f};
+        unsigned long long word[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v2f pt = P[j][e] * AB + Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
+                pt = pt + magic;
+                const int ix = (short)__float_as_int(pt.x), iy = (short)__float_as_int(pt.y);
+                v[e] = c[iy * (DP_DW * 4) + ix];
+            }
+            word[j] = __ballot(v[0] < v[1]);
+        }
+        if (lane < 4) {
+            unsigned long long o = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+            reinterpret_cast<unsigned long long*>(desc + ((size_t)slot * max_kp + idx) * 32)[lane] = o;
+        }
+        // the next keypoint's staging must not overtake these LDS reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                         int slot_base, int nslots, const uint32_t* kp_key, const uint32_t* kp_level,
+                         const int32_t* kp_count, int32_t* kp_mom, slamfe_keypoint* kps, float* kp_rot,
+                         int max_kp, int mode, int patch_size)
+{
+    if (mode == SLAMFE_MODE_ORB) {
+        // about four keypoints per wavefront when the level quotas are met exactly;
+        // the kernel loops, so any count up to max_kp is covered
+        long long est = 0;
+        for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
+        if (est < 64 || est > max_kp) est = max_kp;
+        hipLaunchKernelGGL(k_orient, frame_grid((int)((est + 15) / 16), nframes), dim3(256), 0, s, g, pyr,
+                           slot_base, nslots, kp_key, kp_level, kp_count,
+                           reinterpret_cast<int2*>(kp_mom), max_kp, nframes);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_finish, frame_grid((max_kp + 255) / 256, nframes), dim3(256), 0, s, g,
+                       slot_base, nslots, kp_key, kp_level, kp_count,
+                       reinterpret_cast<const int2*>(kp_mom), kps, reinterpret_cast<float2*>(kp_rot),
+                       max_kp, mode, patch_size, nframes);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* blur,
+                           int slot_base, int nslots, const uint32_t* kp_key,
+                           const uint32_t* kp_level, const int32_t* kp_count,
+                           const float* kp_rot, uint8_t* desc, int max_kp)
+{
+    // about four keypoints per wavefront when the level quotas are met exactly
+    // (cv::ORB), a wavefront per four slots of capacity otherwise; the kernel loops
+    long long est = 0;
+    for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
+    if (est < 64 || est > max_kp) est = max_kp;
+    hipLaunchKernelGGL(k_describe, frame_grid((int)((est + 15) / 16), nframes), dim3(256), 0, s, g, blur,
+                       slot_base, nslots, kp_key, kp_level, kp_count,
+                       reinterpret_cast<const float2*>(kp_rot), desc, max_kp, nframes);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,584 @@
+// slamfe_k_image.hip -- frame ingest, pyramid, fused FAST + blur
+#include "slamfe_device.h"
+
+// ---------------------------------------------------------------------------
+// K1  frame ingest: gray copy or BGR -> gray into pyramid level 0
+//     (cv::cvtColor(frame, frame, COLOR_BGR2GRAY), Init.cc:75)
+// ---------------------------------------------------------------------------
+// A lane produces 16 pixels (one 16-byte store; rows are padded to 64 bytes, so
+// the store may run past w inside the row).  Gray rows that are 16-byte aligned
+// are copied with one 16-byte load; everything else goes pixel by pixel.
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ in, int w, int h,
+                                                int stride, size_t frame_stride, int channels,
+                                                uint8_t* __restrict__ pyr, uint32_t frame_bytes,
+                                                int pitch, int aligned16)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const uint8_t* src = in + (size_t)f * frame_stride + (size_t)y * stride;
+    uint4 o;
+    if (channels == 1 && aligned16 && x + 16 <= w) {
+        o = *reinterpret_cast<const uint4*>(src + x);
+    } else {
+        uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int xx = x + k;
+            uint32_t v = 0;
+            if (xx < w) {
+                if (channels == 3) {
+                    int b = src[3 * xx], gg = src[3 * xx + 1], r = src[3 * xx + 2];
+                    v = (uint32_t)((b * SLAMFE_B2Y + gg * SLAMFE_G2Y + r * SLAMFE_R2Y +
+                                    (1 << (SLAMFE_GRAY_SHIFT - 1))) >> SLAMFE_GRAY_SHIFT);
+                } else {
+                    v = src[xx];
+                }
+            }
+            wd[k >> 2] |= v << (8 * (k & 3));
+        }
+        o = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
+    *reinterpret_cast<uint4*>(pyr + (size_t)f * frame_bytes + (size_t)y * pitch + x) = o;
+}
+
+// ---------------------------------------------------------------------------
+// K0  scaled ingest: cv::resize(frame, frame, Size(), fx, fy) on the BGR frame
+//     (Init.cc:103, Init.cc:126; INTER_LINEAR, 11-bit fixed point) fused with
+//     the BGR -> gray conversion of Init.cc:75.  A lane produces 4 pixels: the
+//     resized BGR values (optionally stored, the host still needs that frame
+//     for Init.cc:294) and their gray values as one dword of pyramid level 0.
+//     xt[dx] = {sx | single << 31, a0 | a1 << 16}, yt[dy] = {y0 | y1 << 16, b0 | b1 << 16}.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest_scaled(const uint8_t* __restrict__ in, int stride,
+                                                       const uint2* __restrict__ xt,
+                                                       const uint2* __restrict__ yt, int dw, int dh,
+                                                       uint8_t* __restrict__ gray, int gpitch,
+                                                       uint8_t* __restrict__ bgr_out, int bpitch)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const uint2 ty = yt[y];
+    const uint8_t* S0 = in + (size_t)(ty.x & 0xffffu) * stride;
+    const uint8_t* S1 = in + (size_t)(ty.x >> 16) * stride;
+    const int b0 = (int)(ty.y & 0xffffu), b1 = (int)(ty.y >> 16);
+    uint32_t g4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (x + k >= dw) break;
+        const uint2 tx = xt[x + k];
+        const int sx = (int)(tx.x & 0x7fffffffu) * 3;
+        const bool single = tx.x >> 31;
+        const int a0 = (int)(tx.y & 0xffffu), a1 = (int)(tx.y >> 16);
+        int v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int r0, r1;
+            if (single) {
+                r0 = S0[sx + c] * 2048;
+                r1 = S1[sx + c] * 2048;
+            } else {
+                r0 = S0[sx + c] * a0 + S0[sx + 3 + c] * a1;
+                r1 = S1[sx + c] * a0 + S1[sx + 3 + c] * a1;
+            }
+            int t = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v[c] = min(max(t, 0), 255);
+        }
+        if (bgr_out) {
+            uint8_t* o = bgr_out + (size_t)y * bpitch + (size_t)(x + k) * 3;
+            o[0] = (uint8_t)v[0];
+            o[1] = (uint8_t)v[1];
+            o[2] = (uint8_t)v[2];
+        }
+        uint32_t gv = (uint32_t)((v[0] * SLAMFE_B2Y + v[1] * SLAMFE_G2Y + v[2] * SLAMFE_R2Y +
+                                  (1 << (SLAMFE_GRAY_SHIFT - 1))) >> SLAMFE_GRAY_SHIFT);
+        g4 |= gv << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(gray + (size_t)y * gpitch + x) = g4;
+}
+
+// ---------------------------------------------------------------------------
+// K2  pyramid: level l from level l-1, INTER_LINEAR_EXACT fixed point
+//     (the cumulative resize chain inside cv::ORB).
+//
+// taps: ofs | c1 << 16 per destination column / row (host-computed in double).
+// A lane produces 4 adjacent pixels and stores them as one dword.  The source
+// bytes of a row come from three aligned dwords starting at (ofs[0] & ~3); the
+// two taps of each pixel are cut out with v_alignbyte, widened to a 16-bit pair
+// and combined with their 8.8 weights by v_dot2_u32_u16; the vertical blend of
+// the two 8.8 row results is one more v_dot2 with the rounding constant as the
+// addend:  out = (h0*w0 + h1*w1 + 2^15) >> 16.
+// ---------------------------------------------------------------------------
+typedef unsigned short slamfe_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
+{
+    union { uint32_t u; slamfe_us2 v; } c;
+    c.u = x;
+    return c.v;
+}
+
+// A wavefront produces RS_ROWS consecutive destination rows.  Everything that
+// depends on the column only (source offset, byte selection, tap weights of the
+// lane's 4 pixels) is decoded once per column block; the horizontal pass of a
+// source row (4 values of 8.8 fixed point, two dwords) is computed once and used
+// by both destination rows that blend it (consecutive destination rows share a
+// source row: 1.2 source rows per destination row instead of 2).
+#define RS_ROWS 4
+
+__global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nframes,
+                                                uint8_t* __restrict__ pyr,
+                                                const uint32_t* __restrict__ taps)
+{
+    const slamfe_dev_level& S = g.lv[l - 1];
+    const slamfe_dev_level& D = g.lv[l];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int y_first = (wg_item() * 4 + wv) * RS_ROWS;
+    const int f = wg_frame();
+    if (f >= nframes || y_first >= D.h) return;
+    const int y_end = min(y_first + RS_ROWS, D.h);
+    const uint8_t* src = pyr + (size_t)f * g.frame_bytes + S.off;
+    uint8_t* dst = pyr + (size_t)f * g.frame_bytes + D.off;
+    const int spitch = S.pitch, dpitch = D.pitch;
+    for (int x = (threadIdx.x & 63) * 4; x < D.w; x += 256) {
+        // the tap table is padded with zero entries to a multiple of 4 per level
+        const uint4 tx = *reinterpret_cast<const uint4*>(taps + D.tap_x + x);
+        const uint32_t txs[4] = {tx.x, tx.y, tx.z, tx.w};
+        const uint32_t a = (txs[0] & 0xffffu) & ~3u; // aligned start of the 12 source bytes
+        uint32_t sh[4], sel[4];
+        slamfe_us2 cv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t o = (txs[k] & 0xffffu) - a; // 0 .. 10
+            const uint32_t c1 = txs[k] >> 16;
+            cv[k] = as_us2((256u - c1) | (c1 << 16));
+            sh[k] = o;
+            sel[k] = o >> 2;
+        }
+        // horizontal pass of one source row: the 4 pixels' 8.8 values, two per dword.
+        // 12 source bytes; bytes past the row end are read but carry weight 0
+        auto hpass = [&](uint32_t p0, uint32_t p1, uint32_t p2) -> uint2 {
+            uint32_t h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t lo = sel[k] == 0 ? p0 : (sel[k] == 1 ? p1 : p2);
+                uint32_t hi = sel[k] == 0 ? p1 : (sel[k] == 1 ? p2 : 0u);
+                uint32_t q = __builtin_amdgcn_alignbyte(hi, lo, sh[k]); // bytes o, o+1 in bits 0..15
+                q = __builtin_amdgcn_perm(0u, q, 0x0c010c00u);          // widen: 0x00 b1 0x00 b0
+                h[k] = __builtin_amdgcn_udot2(as_us2(q), cv[k], 0u, false); // 8.8, <= 65280
+            }
+            return make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        };
+        // walk the source rows the strip needs in order; the next row's 12 bytes are
+        // requested before the current row is processed
+        int y = y_first;
+        uint32_t ty = taps[D.tap_y + y];
+        int yo = (int)(ty & 0xffffu);
+        uint32_t w1 = ty >> 16;
+        int yo1 = yo + (w1 ? 1 : 0);
+        int sy = yo;
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(src + (size_t)sy * spitch + a);
+        uint32_t p0 = r[0], p1 = r[1], p2 = r[2];
+        uint2 Hprev = make_uint2(0, 0), Hcur = make_uint2(0, 0);
+        while (y < y_end) { // uniform
+            const int nsy = min(sy + 1, S.h - 1);
+            const uint32_t* rn = reinterpret_cast<const uint32_t*>(src + (size_t)nsy * spitch + a);
+            const uint32_t n0 = rn[0], n1 = rn[1], n2 = rn[2];
+            Hprev = Hcur;
+            Hcur = hpass(p0, p1, p2);
+            while (y < y_end && yo1 == sy) { // destination rows whose second source row is sy
+                const uint2 H0 = yo == sy ? Hcur : Hprev;
+                const slamfe_us2 wv2 = as_us2((256u - w1) | (w1 << 16));
+                // pair the two rows' values of each pixel: (h0, h1) -> one v_dot2 with the
+                // rounding constant as the addend: out = (h0*w0 + h1*w1 + 2^15) >> 16
+                const uint32_t e0 = __builtin_amdgcn_perm(Hcur.x, H0.x, 0x05040100u); // px0: low halves
+                const uint32_t e1 = __builtin_amdgcn_perm(Hcur.x, H0.x, 0x07060302u); // px1: high halves
+                const uint32_t e2 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x05040100u);
+                const uint32_t e3 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x07060302u);
+                uint32_t v0 = __builtin_amdgcn_udot2(as_us2(e0), wv2, 1u << 15, false) >> 16;
+                uint32_t v1 = __builtin_amdgcn_udot2(as_us2(e1), wv2, 1u << 15, false) >> 16;
+                uint32_t v2 = __builtin_amdgcn_udot2(as_us2(e2), wv2, 1u << 15, false) >> 16;
+                uint32_t v3 = __builtin_amdgcn_udot2(as_us2(e3), wv2, 1u << 15, false) >> 16;
+                const uint32_t out = min(v0, 255u) | (min(v1, 255u) << 8) | (min(v2, 255u) << 16) |
+                                     (min(v3, 255u) << 24);
+                // rows are padded to a multiple of 64 bytes: the dword store stays in the row
+                *reinterpret_cast<uint32_t*>(dst + (size_t)y * dpitch + x) = out;
+                if (++y < y_end) {
+                    ty = taps[D.tap_y + y];
+                    yo = (int)(ty & 0xffffu);
+                    w1 = ty >> 16;
+                    yo1 = yo + (w1 ? 1 : 0);
+                }
+            }
+            ++sy;
+            p0 = n0;
+            p1 = n1;
+            p2 = n2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3+K6  FAST-9/16 (segment test, score, strict 3x3 NMS, border filter) fused
+//        with the 7x7 sigma=2 blur of the same level.
+//        (detector->detect, Init.cc:76, per level inside cv::ORB; and the
+//        GaussianBlur(7x7, 2) cv::ORB applies before describing, Init.cc:78.)
+//
+// One workgroup = one 64x16 tile of one level of one frame.  The tile plus a
+// 4-px halo is read from HBM once (aligned dwords, REFLECT_101 at the image
+// border) into LDS and feeds both computations:
+//
+//  FAST   pass B: every pixel of the tile + 1-px ring gets the 4-point
+//                 pretest (any arc of 9 holds one pixel of each opposite pair,
+//                 so both max(p0,p8) and max(p4,p12) must exceed v+t, or both
+//                 mins lie below v-t); survivors are compacted into an LDS list
+//         pass C: full score for list entries only (dense lanes): max over the
+//                 16 arcs of min(d) and of min(-d), minus 1
+//         pass D: NMS of list entries against the LDS score tile; keypoints
+//                 inside the ORB border go to the tile's candidate list and to
+//                 the level's score histogram
+//  blur   rows:   v_dot4_u32_u8 of byte windows cut out with v_alignbyte
+//                 (3.5 VALU ops per output), 16-bit sums to LDS
+//         cols:   v_dot2_u32_u16 per tap, round, saturate, 4 pixels per store
+// ---------------------------------------------------------------------------
+#define FL_W (TW + 32)         /* LDS tile row: image columns x0-16 .. x0+79, six 16-byte pieces */
+#define FL_WD (FL_W / 4)
+#define FL_X0 12               /* byte column of image column x0-4 (the first one that is used) */
+#define FL_H (TH + 8)          /* 24 rows: y0-4 .. y0+19 */
+#define FB_COLS (TW + 8)       /* used columns: x0-4 .. x0+67 = 18 dwords */
+#define FB_COLD (FB_COLS / 4)
+#define FS_W (TW + 2)          /* score tile: 66 x 18 */
+#define FS_H (TH + 2)
+#define FS_N (FS_W * FS_H)     /* 1188 */
+#define BR_H (TH + 6)          /* rows of blur row sums: 22 */
+
+__device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
+{
+    // ring pixel offsets in the LDS tile (pitch FL_W)
+    constexpr int R[16][2] = SLAMFE_FAST_RING_INIT;
+    int v = c[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[R[k][0] + R[k][1] * FL_W];
+    // min / max over every arc of 9 contiguous ring pixels:
+    // arc(s) = d[s..s+8] = three runs of three
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int a = d[k], b = d[(k + 1) & 15], e = d[(k + 2) & 15];
+        mn3[k] = min(a, min(b, e));
+        mx3[k] = max(a, max(b, e));
+    }
+    int A = INT_MIN, Bn = INT_MAX;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int mn9 = min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
+        int mx9 = max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
+        A = max(A, mn9);   // ring darker than centre by at least A on some arc
+        Bn = min(Bn, mx9); // ring brighter than centre by at least -Bn on some arc
+    }
+    int m = max(A, -Bn);
+    // corner <=> some arc has all |d| > thr on one side; score = that margin - 1
+    return m > thr ? m - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
+                                                   uint8_t* __restrict__ blur, int nframes, int thr,
+                                                   int edge, uint32_t* __restrict__ cand,
+                                                   uint32_t* __restrict__ cand_cnt)
+{
+    __shared__ uint32_t tile32[FL_H * FL_WD];
+    __shared__ uint32_t sc32[(FS_N + 3) / 4];
+    __shared__ uint32_t rows32[BR_H * TW / 2];
+    __shared__ uint16_t pos[FS_N];
+    __shared__ uint32_t list[SLAMFE_TILE_CAND];
+    __shared__ uint32_t nlist, npos;
+    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
+
+    const int t = wg_item(), f = wg_frame(), tid = threadIdx.x;
+    if (f >= nframes) return;
+    const int l = find_level_by_tile(g, t);
+    const slamfe_dev_level L = g.lv[l];
+    const int tl = t - L.tile_base;
+    const int x0 = (tl % L.tiles_x) * TW, y0 = (tl / L.tiles_x) * TH;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
+
+    if (tid == 0) {
+        nlist = 0;
+        npos = 0;
+    }
+    // ---- tile load: 24 rows x six aligned 16-byte pieces (columns x0-16 .. x0+79;
+    // columns x0-4 .. x0+67 are used).  Rows reflect at the top / bottom border by
+    // index; pieces outside the row are zero, bytes past w inside the row's
+    // padding are don't-care until the fix-up below.
+    if (tid < FL_H * 6) {
+        int ly = tid / 6, pc = tid - ly * 6;
+        int gy = reflect101(y0 - 4 + ly, L.h);
+        int gx = x0 - 16 + 16 * pc;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gx >= 0 && gx < L.pitch)
+            v = *reinterpret_cast<const uint4*>(img + (size_t)gy * L.pitch + gx);
+        *reinterpret_cast<uint4*>(&tile32[ly * FL_WD + 4 * pc]) = v;
+    }
+    for (int i = tid; i < (FS_N + 3) / 4; i += 256) sc32[i] = 0;
+    __syncthreads();
+    // REFLECT_101 at the left / right image border (the blur reads 3 px across
+    // it): copy the mirrored bytes inside LDS.  Only border tiles take this.
+    {
+        const bool left = x0 == 0, right = x0 + TW + 3 >= L.w;
+        if (left || right) { // uniform per workgroup
+            uint8_t* tb = reinterpret_cast<uint8_t*>(tile32);
+            if (tid < FL_H * 8) {
+                int ly = tid >> 3, k = tid & 7; // k 0..2: left side, 4..6: right side
+                if (left && k < 3) {
+                    // column -(k+1) <- column k+1
+                    tb[ly * FL_W + FL_X0 + 4 - (k + 1)] = tb[ly * FL_W + FL_X0 + 4 + (k + 1)];
+                } else if (right && k >= 4 && k < 7) {
+                    int x = L.w + (k - 4); // <- column 2(w-1) - x
+                    int lx = x - (x0 - 16), sx = 2 * (L.w - 1) - x - (x0 - 16);
+                    if (lx < FL_W && sx >= 0) tb[ly * FL_W + lx] = tb[ly * FL_W + sx];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- FAST pass B: pretest on the tile + 1-px ring, 8 pixels per task.
+    // Task = (score row sy of 18, dword pair m of 9); its pixels are LDS bytes
+    // lx = 8m .. 8m+7 of row ly = sy + 3.  Bytes are widened to 16-bit pairs
+    // (pixels 0,2 and 1,3 of a dword) so that packed 16-bit min / max / sub
+    // handle two pixels per operation; a negative difference flags a survivor.
+    // (162 tasks: three wave passes; with 4 pixels per task it took six.)
+    {
+        typedef short v2s __attribute__((ext_vector_type(2)));
+        union pk { uint32_t u; v2s v; };
+        const int blo = max(3, edge - 1);
+        // tiles that lie entirely in the discarded border band skip FAST
+        const bool any_fast = x0 + TW + 1 > blo && x0 - 1 < L.w - blo && y0 + TH + 1 > blo &&
+                              y0 - 1 < L.h - blo;
+        const bool interior = x0 - 1 >= blo && x0 + TW <= L.w - blo - 1 && y0 - 1 >= blo &&
+                              y0 + TH <= L.h - blo - 1;
+        const v2s t2 = {(short)thr, (short)thr};
+        // survivors among the 4 pixels of dword C (ring pixels: U above, D below,
+        // L3 / R3 three to the left / right), one flag bit per pixel
+        auto pretest4 = [&](uint32_t C, uint32_t U, uint32_t D, uint32_t L3, uint32_t R3) -> uint32_t {
+            uint32_t flags = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                pk v, p0, p8, p4, p12;
+                if (half == 0) {
+                    v.u = C & 0x00ff00ffu; p0.u = D & 0x00ff00ffu; p8.u = U & 0x00ff00ffu;
+                    p4.u = R3 & 0x00ff00ffu; p12.u = L3 & 0x00ff00ffu;
+                } else { // bytes 1 and 3, widened by one v_perm each
+                    v.u = __builtin_amdgcn_perm(0u, C, 0x0c030c01u);
+                    p0.u = __builtin_amdgcn_perm(0u, D, 0x0c030c01u);
+                    p8.u = __builtin_amdgcn_perm(0u, U, 0x0c030c01u);
+                    p4.u = __builtin_amdgcn_perm(0u, R3, 0x0c030c01u);
+                    p12.u = __builtin_amdgcn_perm(0u, L3, 0x0c030c01u);
+                }
+                v2s hi = __builtin_elementwise_min(__builtin_elementwise_max(p0.v, p8.v),
+                                                   __builtin_elementwise_max(p4.v, p12.v));
+                v2s lo = __builtin_elementwise_max(__builtin_elementwise_min(p0.v, p8.v),
+                                                   __builtin_elementwise_min(p4.v, p12.v));
+                pk r1, r2;
+                r1.v = (v.v + t2) - hi; // < 0  <=>  hi > v + t
+                r2.v = lo - (v.v - t2); // < 0  <=>  lo < v - t
+                uint32_t neg = (r1.u | r2.u) & 0x80008000u;
+                // pair element 0 -> pixel `half`, element 1 -> pixel 2 + half
+                flags |= ((neg >> 15) & 1u) << half;
+                flags |= (neg >> 31) << (2 + half);
+            }
+            return flags;
+        };
+        for (int i = tid; any_fast && i < FS_H * (FB_COLD / 2); i += 256) {
+            int sy = i / (FB_COLD / 2), m = i - sy * (FB_COLD / 2);
+            int ly = sy + 3;
+            const uint32_t* row = &tile32[ly * FL_WD + FL_X0 / 4 + 2 * m];
+            uint32_t C0 = row[0], C1 = row[1], Cp = row[-1], Cn = row[2];
+            uint32_t U0 = row[-3 * FL_WD], U1 = row[-3 * FL_WD + 1];
+            uint32_t D0 = row[3 * FL_WD], D1 = row[3 * FL_WD + 1];
+            uint32_t flags = pretest4(C0, U0, D0, __builtin_amdgcn_alignbyte(C0, Cp, 1),
+                                      __builtin_amdgcn_alignbyte(C1, C0, 3)) |
+                             pretest4(C1, U1, D1, __builtin_amdgcn_alignbyte(C1, C0, 1),
+                                      __builtin_amdgcn_alignbyte(Cn, C1, 3)) << 4;
+            // pixel k is a score position iff lx = 8m+k in [3, 68] and the image
+            // position is inside the band that can still yield a keypoint:
+            // keypoints outside [edge, w-edge) x [edge, h-edge) are discarded by
+            // the ORB border filter, and NMS looks one pixel further, so scores
+            // are needed on [lo, w-lo) x [lo, h-lo) with lo = max(3, edge-1)
+            // (tiles whose score area lies inside that band need the column rule only)
+            uint32_t valid;
+            if (interior) { // uniform
+                valid = m == 0 ? 0xf8u : (m == FB_COLD / 2 - 1 ? 0x1fu : 0xffu);
+            } else {
+                int gy = y0 - 1 + sy, gxb = x0 - 4 + 8 * m;
+                int kmin = max(3 - 8 * m, blo - gxb), kmax = min(FS_W + 2 - 8 * m, L.w - blo - 1 - gxb);
+                kmin = max(kmin, 0);
+                kmax = min(kmax, 7);
+                valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
+                            ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
+            }
+            flags &= valid;
+            // wave-level compaction: exclusive prefix of the per-lane counts
+            // (0..8) from four ballots, one LDS atomic per wave.  (A per-lane
+            // atomicAdd of the count is turned by the compiler into a serial
+            // loop over the lanes and made the kernel 12 % slower.)
+            const uint32_t c = (uint32_t)__popc(flags);
+            const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u),
+                                     m3 = __ballot(c & 8u);
+            const unsigned long long act = __ballot(1);
+            uint32_t pre = lane_rank(m0) + 2u * lane_rank(m1) + 4u * lane_rank(m2) + 8u * lane_rank(m3);
+            const uint32_t tot = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) +
+                                 4u * (uint32_t)__popcll(m2) + 8u * (uint32_t)__popcll(m3);
+            const uint32_t rank = lane_rank(act);
+            uint32_t base = 0;
+            if (tot) { // wave-uniform
+                if (rank == 0) base = atomicAdd(&npos, tot);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + pre;
+                int sbase = sy * FS_W + 8 * m - 3;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (flags & (1u << k)) pos[base++] = (uint16_t)(sbase + k);
+            }
+        }
+    }
+
+    // ---- blur row pass: task = (row r of 22, group k of 8) -> 8 sums
+    // (176 tasks: three wave passes)
+    {
+        const uint32_t KA = 18u | (34u << 8) | (49u << 16) | (55u << 24); // taps 0..3
+        const uint32_t KB = 49u | (34u << 8) | (18u << 16);               // taps 4..6, 0
+        // the 4 sums of the dword whose window is (d0, d1, d2): output c = 4k+j reads
+        // bytes (j+1 .. j+7) of the 12-byte window
+        auto rows4 = [&](uint32_t d0, uint32_t d1, uint32_t d2) -> uint2 {
+            uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0, false);
+            s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, s0, false);
+            uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0, false);
+            s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, s1, false);
+            uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0, false);
+            s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, s2, false);
+            uint32_t s3 = __builtin_amdgcn_udot4(d1, KA, 0, false);
+            s3 = __builtin_amdgcn_udot4(d2, KB, s3, false);
+            // sums are <= 257 * 255 = 65535: two per dword
+            return make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+        };
+        for (int i = tid; i < BR_H * 8; i += 256) {
+            int r = i >> 3, k = i & 7;
+            const uint32_t* p = &tile32[(r + 1) * FL_WD + FL_X0 / 4 + 2 * k]; // columns x0-4+8k .. +15
+            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+            uint2 a = rows4(d0, d1, d2), c = rows4(d1, d2, d3);
+            *reinterpret_cast<uint4*>(&rows32[r * (TW / 2) + 4 * k]) = make_uint4(a.x, a.y, c.x, c.y);
+        }
+    }
+    __syncthreads();
+
+    // ---- FAST pass C: full score of the pretest survivors
+    const uint32_t np = npos;
+    for (uint32_t k = tid; k < np; k += 256) {
+        int i = pos[k];
+        int sy = i / FS_W, sx = i - sy * FS_W;
+        sc[i] = (uint8_t)fast_score_lds(&tile[(sy + 3) * FL_W + FL_X0 + sx + 3], thr);
+    }
+
+    // ---- blur column pass: task = (row r of 16, group k of 16) -> 4 pixels
+    {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        constexpr int K[7] = SLAMFE_GAUSS7_INIT;
+        int r = tid >> 4, k = tid & 15;
+        int gy = y0 + r, gx = x0 + 4 * k;
+        if (gy < L.h && gx < L.w) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                uint2 v = *reinterpret_cast<const uint2*>(&rows32[(r + i) * (TW / 2) + 2 * k]);
+                us2 lo, hi, klo, khi;
+                lo.x = (unsigned short)v.x; lo.y = (unsigned short)(v.x >> 16);
+                hi.x = (unsigned short)v.y; hi.y = (unsigned short)(v.y >> 16);
+                klo.x = (unsigned short)K[i]; klo.y = 0;
+                khi.x = 0; khi.y = (unsigned short)K[i];
+                a0 = __builtin_amdgcn_udot2(lo, klo, a0, false);
+                a1 = __builtin_amdgcn_udot2(lo, khi, a1, false);
+                a2 = __builtin_amdgcn_udot2(hi, klo, a2, false);
+                a3 = __builtin_amdgcn_udot2(hi, khi, a3, false);
+            }
+            a0 = min((a0 + 32768u) >> 16, 255u);
+            a1 = min((a1 + 32768u) >> 16, 255u);
+            a2 = min((a2 + 32768u) >> 16, 255u);
+            a3 = min((a3 + 32768u) >> 16, 255u);
+            uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off + (size_t)gy * L.pitch + gx;
+            // rows are padded to a multiple of 64 bytes, so the dword store stays
+            // inside the row even when it covers pixels beyond w
+            *reinterpret_cast<uint32_t*>(out) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+        }
+    }
+    __syncthreads();
+
+    // ---- FAST pass D: NMS of the survivors, border filter, emission
+    for (uint32_t k = tid; k < np; k += 256) {
+        int i = pos[k];
+        int s = sc[i];
+        int sy = i / FS_W, sx = i - sy * FS_W;
+        if (s > 0 && sy >= 1 && sy <= TH && sx >= 1 && sx <= TW) {
+            const uint8_t* p = &sc[i];
+            int m = max(max(max(p[-1], p[1]), max(p[-FS_W - 1], p[-FS_W])),
+                        max(max(p[-FS_W + 1], p[FS_W - 1]), max(p[FS_W], p[FS_W + 1])));
+            int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+            if (s > m && gx >= edge && gx < L.w - edge && gy >= edge && gy < L.h - edge) {
+                uint32_t q = atomicAdd(&nlist, 1u);
+                list[q] = SLAMFE_KEY(gx, gy, s);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = nlist;
+    size_t tg = (size_t)f * g.total_tiles + t;
+    if (tid < n) cand[tg * SLAMFE_TILE_CAND + tid] = list[tid];
+    if (tid == 0) cand_cnt[tg] = n;
+}
+
+int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int stride,
+                         size_t frame_stride, int channels, int nframes, uint8_t* pyr,
+                         uint32_t frame_bytes, int pitch)
+{
+    dim3 grid((w + 1023) / 1024, (h + 3) / 4, nframes);
+    int aligned16 = ((uintptr_t)d_in % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;
+    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, d_in, w, h, stride, frame_stride, channels,
+                       pyr, frame_bytes, pitch, aligned16);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_ingest_scaled(hipStream_t s, const uint8_t* d_in, int stride, const uint32_t* xt,
+                                const uint32_t* yt, int dw, int dh, uint8_t* gray, int gpitch,
+                                uint8_t* bgr_out, int bpitch)
+{
+    dim3 grid((dw + 255) / 256, (dh + 3) / 4);
+    hipLaunchKernelGGL(k_ingest_scaled, grid, dim3(256), 0, s, d_in, stride,
+                       reinterpret_cast<const uint2*>(xt), reinterpret_cast<const uint2*>(yt), dw, dh,
+                       gray, gpitch, bgr_out, bpitch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
+                          const uint32_t* taps)
+{
+    for (int l = 1; l < g.nlevels; ++l) {
+        hipLaunchKernelGGL(k_resize, frame_grid((g.lv[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nframes), dim3(256), 0, s, g, l,
+                           nframes, pyr, taps);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt)
+{
+    hipLaunchKernelGGL(k_fast_blur, frame_grid(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur,
+                       nframes, thr, edge, cand, cand_cnt);
+    LAUNCH_CHECK();
+    return 0;
+}

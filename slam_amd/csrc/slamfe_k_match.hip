@@ -1,0 +1,552 @@
+// slamfe_k_match.hip -- brute-force Hamming k=2: matrix-core and vector-ALU kernels, merges
+#include "slamfe_device.h"
+
+// ---------------------------------------------------------------------------
+// K8  brute-force Hamming k=2 (BFMatcher::knnMatch, Init.cc:131) + ratio test
+//     (Init.cc:146-147).
+//
+// Two kernels give identical results: k_match_mfma (matrix cores, further down)
+// and k_match (vector ALU): a lane owns QPT query rows in registers (8 dwords
+// each; QPT = 1 is what the plan uses), train rows are staged through LDS, one
+// comparison is 8 v_xor + 8 accumulating v_bcnt; the running top-2 is kept as
+// packed keys (distance << 23 | train row), for which integer min *is* the
+// (distance, index) order of knnMatch.  The train set is cut into chunks;
+// k_match_merge folds the per-chunk top-2.
+// ---------------------------------------------------------------------------
+// Frame-slot addressing for batched frame-vs-frame matching: pair z (blockIdx.z)
+// matches slot (q_base + z) % nslots against slot (t_base + z) % nslots; rows
+// and counts of slot s are at desc + s * cap * 32 and count + s.  nslots = 0
+// means "plain pointers, one pair".
+struct slamfe_pair_slots {
+    int q_base, t_base, nslots;
+};
+
+// One 256-bit comparison and top-2 update: 8 v_xor + 8 chained accumulating
+// v_bcnt + key pack + v_min + v_med3 = 19 VALU operations.
+__device__ __forceinline__ void match_row(const uint32_t (&q)[8], const uint32_t (&t)[8], uint32_t j,
+                                          uint32_t& b1, uint32_t& b2)
+{
+    uint32_t d, x0 = q[0] ^ t[0];
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x0));
+#pragma unroll
+    for (int e = 1; e < 8; ++e) {
+        uint32_t x = q[e] ^ t[e];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+    }
+    uint32_t key = (d << SLAMFE_MKEY_SHIFT) | j;
+    // b1 <= b2 always, so the new second best is the median of (key, b1, b2)
+    uint32_t nb2;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(nb2) : "v"(key), "v"(b1), "v"(b2));
+    b1 = min(key, b1);
+    b2 = nb2;
+}
+
+// Train rows are staged through LDS in blocks of 128 rows (4 KiB, one 16-byte
+// piece per thread, coalesced); every lane then reads the same row address
+// (an LDS broadcast: no bank conflicts), two ds_read_b128 per row, so the row
+// sits in 8 VGPRs while QPT comparisons use it.  The next block's global load
+// is issued before the current block is consumed and written to the other LDS
+// buffer afterwards.
+#define MATCH_STAGE_ROWS 128
+
+// Work decomposition: one workgroup = (pair, block of 256*QPT queries, chunk of
+// chunk_rows train rows).  The grid is one-dimensional and sized for the
+// capacity; a workgroup derives its work item from the *actual* row counts so
+// that the busy workgroups are the first ones of the grid: workgroups are dealt
+// round-robin to the 8 XCDs, and a grid whose idle workgroups recur with a
+// period of 8 would leave whole XCDs empty.
+struct slamfe_match_geo {
+    int cap;        // row capacity of a frame slot / of the query array
+    int chunk_rows; // train rows per workgroup
+    int nchunks;    // chunks the partial buffer is laid out for
+    int npairs;
+    int part_sq, part_sc; // partial index = chunk * part_sc + query * part_sq (uint2 units)
+};
+
+template <int QPT>
+__global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ query, int nq_imm,
+                                               const int32_t* __restrict__ nq_dev,
+                                               const uint32_t* __restrict__ train, int nt_imm,
+                                               const int32_t* __restrict__ nt_dev,
+                                               uint32_t* __restrict__ part, slamfe_pair_slots ps,
+                                               slamfe_match_geo mg)
+{
+    __shared__ uint4 stage[2][MATCH_STAGE_ROWS * 2];
+    const int pair = (int)(blockIdx.x % (unsigned)mg.npairs);
+    const int local = (int)(blockIdx.x / (unsigned)mg.npairs);
+    if (ps.nslots) {
+        int sq = (ps.q_base + pair) % ps.nslots, st = (ps.t_base + pair) % ps.nslots;
+        query += (size_t)sq * mg.cap * 8;
+        train += (size_t)st * mg.cap * 8;
+        nq_dev += sq;
+        nt_dev += st;
+        part += (size_t)pair * mg.nchunks * mg.cap * 2;
+    }
+    const int nq = nq_dev ? min(*nq_dev, mg.cap) : nq_imm;
+    const int nt = nt_dev ? min(*nt_dev, mg.cap) : nt_imm;
+    const int real_q = (nq + 256 * QPT - 1) / (256 * QPT);
+    const int real_c = max(1, (nt + mg.chunk_rows - 1) / mg.chunk_rows);
+    if (local >= real_q * real_c) return;
+    const int qb = local / real_c, chunk = local - qb * real_c;
+    const int tid = threadIdx.x;
+    const int qbase = qb * 256 * QPT + tid; // lane owns queries qbase, qbase + 256, ...
+    const int j0 = chunk * mg.chunk_rows;
+    const int j1 = min(nt, j0 + mg.chunk_rows);
+    uint32_t q[QPT][8];
+    uint32_t b1[QPT], b2[QPT];
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        int qi = min(qbase + i * 256, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 8);
+        uint4 lo = p[0], hi = p[1];
+        q[i][0] = lo.x; q[i][1] = lo.y; q[i][2] = lo.z; q[i][3] = lo.w;
+        q[i][4] = hi.x; q[i][5] = hi.y; q[i][6] = hi.z; q[i][7] = hi.w;
+        b1[i] = b2[i] = SLAMFE_MKEY_NONE;
+    }
+    if (j0 < j1) { // uniform per workgroup
+        const uint4* t4 = reinterpret_cast<const uint4*>(train);
+        const int nstages = (j1 - j0 + MATCH_STAGE_ROWS - 1) / MATCH_STAGE_ROWS;
+        // piece `tid` of a stage = 16 bytes at row (tid >> 1), half (tid & 1)
+        auto load_piece = [&](int st) -> uint4 {
+            int row = j0 + st * MATCH_STAGE_ROWS + (tid >> 1);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < j1) v = t4[(size_t)row * 2 + (tid & 1)];
+            return v;
+        };
+        stage[0][tid] = load_piece(0);
+        __syncthreads();
+        for (int st = 0; st < nstages; ++st) {
+            const int cur = st & 1;
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            if (st + 1 < nstages) nxt = load_piece(st + 1);
+            const int jb = j0 + st * MATCH_STAGE_ROWS;
+            const int rows = min(MATCH_STAGE_ROWS, j1 - jb);
+            const uint4* sp = stage[cur];
+            int r = 0;
+            for (; r + 4 <= rows; r += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint4 lo = sp[(r + u) * 2], hi = sp[(r + u) * 2 + 1];
+                    const uint32_t tr[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int i = 0; i < QPT; ++i)
+                        match_row(q[i], tr, (uint32_t)(jb + r + u), b1[i], b2[i]);
+                }
+            }
+            for (; r < rows; ++r) {
+                uint4 lo = sp[r * 2], hi = sp[r * 2 + 1];
+                const uint32_t tr[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int i = 0; i < QPT; ++i) match_row(q[i], tr, (uint32_t)(jb + r), b1[i], b2[i]);
+            }
+            if (st + 1 < nstages) stage[cur ^ 1][tid] = nxt;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        int qi = qbase + i * 256;
+        if (qi < nq) {
+            uint2 o = make_uint2(b1[i], b2[i]);
+            reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K8m  the same brute-force Hamming k=2 on the matrix cores.
+//
+// With train bits a in {0, 1} and query bits mapped to b' = 1 - 2b in {+1, -1},
+//   sum_k a_k * b'_k = popcount(a) - 2 a.b = hamming(a, b) - popcount(b),
+// so one v_mfma_i32_32x32x32_i8 chain over the 256 bit positions (8 MFMAs) gives
+// the exact distances of 32 train rows x 32 queries, minus a per-query constant
+// that does not change the order.  In the result tile the query is the lane
+// (column) and the 16 registers are train rows, so the running top-2 of a query
+// stays in its lane: key = (dot + 256) << 22 | row-in-tile, one v_lshl_add per
+// distance, then v_min / v_med3 as in the VALU kernel.  Per comparison that is 3
+// VALU operations instead of 19; the 8 MFMAs of a tile take 256 cycles per SIMD.
+//
+// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to +-1 bytes in
+// 64 VGPRs per lane) x one chunk of train rows.  Train rows are read packed
+// (32 bytes), expanded to 0/1 bytes into LDS (one dword -> 32 bytes per thread
+// and tile, rows padded to 272 bytes so that the 16-byte fragment reads are
+// conflict-free), double-buffered.  Row indices inside the keys are relative to
+// the current tile (older entries are moved down by 32 per tile: 2 operations
+// per tile instead of re-basing 16 constants) and made absolute at the end.
+// ---------------------------------------------------------------------------
+#define MM_TILE 32
+#define MM_SUB 2 /* tiles per LDS stage (one workgroup barrier per stage) */
+#define MM_ROW 272
+#define MM_BIAS 8192u
+#define MM_SHIFT 22
+typedef int mm_v4i __attribute__((ext_vector_type(4)));
+typedef int mm_v16i __attribute__((ext_vector_type(16)));
+
+// bits pos .. pos+3 of x -> four bytes of 0 / 1 (bit i in byte i)
+__device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x, int pos)
+{
+    return (((x >> pos) & 0xFu) * 0x00204081u) & 0x01010101u;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_match_mfma(const uint32_t* __restrict__ query, int nq_imm,
+                                                    const int32_t* __restrict__ nq_dev,
+                                                    const uint32_t* __restrict__ train, int nt_imm,
+                                                    const int32_t* __restrict__ nt_dev,
+                                                    uint32_t* __restrict__ part, slamfe_pair_slots ps,
+                                                    slamfe_match_geo mg)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sA[2][MM_SUB][MM_TILE * MM_ROW];
+    const int pair = (int)(blockIdx.x % (unsigned)mg.npairs);
+    const int local = (int)(blockIdx.x / (unsigned)mg.npairs);
+    if (ps.nslots) {
+        int sq = (ps.q_base + pair) % ps.nslots, st = (ps.t_base + pair) % ps.nslots;
+        query += (size_t)sq * mg.cap * 8;
+        train += (size_t)st * mg.cap * 8;
+        nq_dev += sq;
+        nt_dev += st;
+        part += (size_t)pair * mg.nchunks * mg.cap * 2;
+    }
+    const int nq = nq_dev ? min(*nq_dev, mg.cap) : nq_imm;
+    const int nt = nt_dev ? min(*nt_dev, mg.cap) : nt_imm;
+    const int real_q = (nq + 255) / 256;
+    const int real_c = max(1, (nt + mg.chunk_rows - 1) / mg.chunk_rows);
+    if (local >= real_q * real_c) return;
+    const int qb256 = local / real_c, chunk = local - qb256 * real_c;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int j0 = chunk * mg.chunk_rows;
+    const int j1 = min(nt, j0 + mg.chunk_rows);
+    const int qfirst = qb256 * 256 + wv * 64 + r; // + 32 for the second block
+
+    if (j0 >= j1) { // an empty train set: every query of the workgroup gets "none"
+        for (int blk = 0; blk < 2; ++blk) {
+            int qi = qfirst + 32 * blk;
+            if (h == 0 && qi < nq)
+                reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
+                    make_uint2(SLAMFE_MKEY_NONE, SLAMFE_MKEY_NONE);
+        }
+        return;
+    }
+
+    // query fragments: lane (r, h) holds bits 16h .. 16h+15 of every dword of its
+    // query row as +-1 bytes
+    mm_v4i B[2][8];
+    int pq[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int qi = min(qfirst + 32 * blk, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t qw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        int pc = 0;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            pc += __popc(qw[kb]);
+            const uint32_t half = (qw[kb] >> (16 * h)) & 0xffffu;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint32_t t = bits4_to_bytes(half, 4 * n);
+                B[blk][kb][n] = (int)(((t << 8) - t) | 0x01010101u); // bit 1 -> 0xff (-1), bit 0 -> 0x01
+            }
+        }
+        pq[blk] = pc;
+    }
+
+    // a stage = MM_SUB tiles; the thread's piece of tile u of a stage: dword
+    // (tid & 7) of row (tid >> 3)
+    auto load_bits = [&](int st, int u) -> uint32_t {
+        const int row = j0 + (st * MM_SUB + u) * MM_TILE + (tid >> 3);
+        return row < j1 ? train[(size_t)row * 8 + (tid & 7)] : 0u;
+    };
+    auto store_tile = [&](int buf, int u, uint32_t bits) {
+        uint4 a, b;
+        a.x = bits4_to_bytes(bits, 0);  a.y = bits4_to_bytes(bits, 4);
+        a.z = bits4_to_bytes(bits, 8);  a.w = bits4_to_bytes(bits, 12);
+        b.x = bits4_to_bytes(bits, 16); b.y = bits4_to_bytes(bits, 20);
+        b.z = bits4_to_bytes(bits, 24); b.w = bits4_to_bytes(bits, 28);
+        uint4* d = reinterpret_cast<uint4*>(&sA[buf][u][(tid >> 3) * MM_ROW + (tid & 7) * 32]);
+        d[0] = a;
+        d[1] = b;
+    };
+    const int ntiles = (j1 - j0 + MM_TILE - 1) / MM_TILE;
+    const int nstages = (ntiles + MM_SUB - 1) / MM_SUB;
+#pragma unroll
+    for (int u = 0; u < MM_SUB; ++u) store_tile(0, u, load_bits(0, u));
+    __syncthreads();
+
+    // result register j of lane half h is train row (j & 3) + 8 (j >> 2) + 4 h of the tile
+    uint32_t cj[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cj[j] = (256u << MM_SHIFT) + MM_BIAS + (uint32_t)((j & 3) + 8 * (j >> 2) + 4 * h);
+    uint32_t b1[2] = {0xffffffffu, 0xffffffffu}, b2[2] = {0xffffffffu, 0xffffffffu};
+
+    for (int st = 0; st < nstages; ++st) {
+        uint32_t nbits[MM_SUB];
+#pragma unroll
+        for (int u = 0; u < MM_SUB; ++u) nbits[u] = st + 1 < nstages ? load_bits(st + 1, u) : 0u;
+#pragma unroll
+        for (int u = 0; u < MM_SUB; ++u) {
+            const int t = st * MM_SUB + u;
+            if (t >= ntiles) break; // uniform
+            const uint8_t* base = &sA[st & 1][u][r * MM_ROW + h * 16];
+            mm_v16i acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const mm_v4i a = *reinterpret_cast<const mm_v4i*>(base + kb * 32);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[0][kb], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[1][kb], acc1, 0, 0, 0);
+            }
+            // entries of earlier tiles move down by one tile
+            b1[0] -= MM_TILE; b2[0] -= MM_TILE; b1[1] -= MM_TILE; b2[1] -= MM_TILE;
+            const int rows = j1 - (j0 + t * MM_TILE); // valid rows of this tile (>= 32: all)
+            if (rows >= MM_TILE) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    uint32_t k0 = ((uint32_t)acc0[j] << MM_SHIFT) + cj[j];
+                    uint32_t k1 = ((uint32_t)acc1[j] << MM_SHIFT) + cj[j];
+                    uint32_t n0, n1;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
+                    b1[0] = min(k0, b1[0]); b2[0] = n0;
+                    b1[1] = min(k1, b1[1]); b2[1] = n1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool ok = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
+                    uint32_t k0 = ok ? ((uint32_t)acc0[j] << MM_SHIFT) + cj[j] : 0xffffffffu;
+                    uint32_t k1 = ok ? ((uint32_t)acc1[j] << MM_SHIFT) + cj[j] : 0xffffffffu;
+                    uint32_t n0, n1;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
+                    b1[0] = min(k0, b1[0]); b2[0] = n0;
+                    b1[1] = min(k1, b1[1]); b2[1] = n1;
+                }
+            }
+        }
+        if (st + 1 < nstages) {
+#pragma unroll
+            for (int u = 0; u < MM_SUB; ++u) store_tile((st + 1) & 1, u, nbits[u]);
+        }
+        __syncthreads();
+    }
+
+    // the two lane halves hold disjoint train rows of the same query: merge, then
+    // make distance and row absolute
+    const uint32_t last = (uint32_t)(ntiles - 1) * MM_TILE;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)b1[blk], 32), o2 = (uint32_t)__shfl_xor((int)b2[blk], 32);
+        const uint32_t m1 = min(b1[blk], o1);
+        const uint32_t m2 = min(max(b1[blk], o1), min(b2[blk], o2));
+        const int qi = qfirst + 32 * blk;
+        if (h == 0 && qi < nq) {
+            auto conv = [&](uint32_t k) -> uint32_t {
+                if (k >= 0xC0000000u) return SLAMFE_MKEY_NONE;
+                const uint32_t d = (k >> MM_SHIFT) - 256u + (uint32_t)pq[blk];
+                const uint32_t row = (k & ((1u << MM_SHIFT) - 1u)) - MM_BIAS + last + (uint32_t)j0;
+                return (d << SLAMFE_MKEY_SHIFT) | row;
+            };
+            reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
+                make_uint2(conv(m1), conv(m2));
+        }
+    }
+}
+
+__device__ __forceinline__ void top2_push(uint32_t k, uint32_t& b1, uint32_t& b2)
+{
+    uint32_t mx = max(k, b1);
+    b1 = min(k, b1);
+    b2 = min(mx, b2);
+}
+
+__device__ __forceinline__ void match_emit(uint32_t b1, uint32_t b2, int qi, float ratio,
+                                           slamfe_match2* __restrict__ out,
+                                           uint64_t* __restrict__ out_keys, int64_t train_base)
+{
+    const uint32_t mask = (1u << SLAMFE_MKEY_SHIFT) - 1u;
+    if (out_keys) {
+        uint64_t k0 = ~0ULL, k1 = ~0ULL;
+        if (b1 != SLAMFE_MKEY_NONE)
+            k0 = ((uint64_t)(b1 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b1 & mask));
+        if (b2 != SLAMFE_MKEY_NONE)
+            k1 = ((uint64_t)(b2 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b2 & mask));
+        out_keys[(size_t)qi * 2] = k0;
+        out_keys[(size_t)qi * 2 + 1] = k1;
+    }
+    if (out) {
+        slamfe_match2 m;
+        m.idx0 = b1 != SLAMFE_MKEY_NONE ? (int32_t)(b1 & mask) : -1;
+        m.idx1 = b2 != SLAMFE_MKEY_NONE ? (int32_t)(b2 & mask) : -1;
+        m.d0 = (uint16_t)(b1 != SLAMFE_MKEY_NONE ? b1 >> SLAMFE_MKEY_SHIFT : 0);
+        m.d1 = (uint16_t)(b2 != SLAMFE_MKEY_NONE ? b2 >> SLAMFE_MKEY_SHIFT : 0);
+        m.nfound = (uint8_t)((m.idx0 >= 0) + (m.idx1 >= 0));
+        m.ratio_pass = (uint8_t)(m.nfound == 2 && (float)m.d0 < ratio * (float)m.d1);
+        m.reserved[0] = m.reserved[1] = 0;
+        out[qi] = m;
+    }
+}
+
+// Fold per-chunk top-2 keys.  Output either match rows (ratio test applied) or
+// 64-bit shard keys (distance << 32 | global train index).
+// LPQ = lanes per query: 1 (a thread walks the few chunks of a frame pair) or
+// 64 (a wavefront strides over the hundreds of chunks of a large train set and
+// folds with a shuffle butterfly; partials are then laid out query-major so the
+// wave reads contiguous keys).
+template <int LPQ>
+__global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict__ part, int nq_imm,
+                                                     const int32_t* __restrict__ nq_dev,
+                                                     const int32_t* __restrict__ nt_dev, int nt_imm,
+                                                     float ratio, slamfe_match2* __restrict__ out,
+                                                     uint64_t* __restrict__ out_keys,
+                                                     int64_t train_base, slamfe_pair_slots ps,
+                                                     slamfe_match_geo mg)
+{
+    const int pair = blockIdx.y;
+    if (ps.nslots) {
+        int sq = (ps.q_base + pair) % ps.nslots, st = (ps.t_base + pair) % ps.nslots;
+        nq_dev += sq;
+        nt_dev += st;
+        part += (size_t)pair * mg.nchunks * mg.cap * 2;
+        out += (size_t)pair * mg.cap;
+    }
+    const int nq = nq_dev ? min(*nq_dev, mg.cap) : nq_imm;
+    const int nt = nt_dev ? min(*nt_dev, mg.cap) : nt_imm;
+    const int used = max(1, (nt + mg.chunk_rows - 1) / mg.chunk_rows);
+    const uint2* p2 = reinterpret_cast<const uint2*>(part);
+    uint32_t b1 = SLAMFE_MKEY_NONE, b2 = SLAMFE_MKEY_NONE;
+    if (LPQ == 1) {
+        int qi = blockIdx.x * 256 + threadIdx.x;
+        if (qi >= nq) return;
+        for (int c = 0; c < used; ++c) {
+            uint2 p = p2[(size_t)c * mg.part_sc + (size_t)qi * mg.part_sq];
+            top2_push(p.x, b1, b2);
+            top2_push(p.y, b1, b2);
+        }
+        match_emit(b1, b2, qi, ratio, out, out_keys, train_base);
+    } else {
+        int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (qi >= nq) return;
+        for (int c = lane; c < used; c += 64) {
+            uint2 p = p2[(size_t)c * mg.part_sc + (size_t)qi * mg.part_sq];
+            top2_push(p.x, b1, b2);
+            top2_push(p.y, b1, b2);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t o1 = (uint32_t)__shfl_xor((int)b1, o), o2 = (uint32_t)__shfl_xor((int)b2, o);
+            uint32_t mx = max(b1, o1);
+            b1 = min(b1, o1);
+            b2 = min(mx, min(b2, o2));
+        }
+        if (lane == 0) match_emit(b1, b2, qi, ratio, out, out_keys, train_base);
+    }
+}
+
+// Merge key sets of several shards ([shard][nq][2], each ascending).
+__global__ __launch_bounds__(256) void k_merge_shard_keys(const uint64_t* __restrict__ keys,
+                                                          int nshards, int nq, float ratio,
+                                                          slamfe_match2* __restrict__ out)
+{
+    int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint64_t b1 = ~0ULL, b2 = ~0ULL;
+    for (int s = 0; s < nshards; ++s)
+        for (int e = 0; e < 2; ++e) {
+            uint64_t k = keys[((size_t)s * nq + qi) * 2 + e];
+            uint64_t mx = k > b1 ? k : b1;
+            b1 = k < b1 ? k : b1;
+            b2 = mx < b2 ? mx : b2;
+        }
+    slamfe_match2 m;
+    m.idx0 = b1 != ~0ULL ? (int32_t)(b1 & 0xffffffffULL) : -1;
+    m.idx1 = b2 != ~0ULL ? (int32_t)(b2 & 0xffffffffULL) : -1;
+    m.d0 = (uint16_t)(b1 != ~0ULL ? b1 >> 32 : 0);
+    m.d1 = (uint16_t)(b2 != ~0ULL ? b2 >> 32 : 0);
+    m.nfound = (uint8_t)((b1 != ~0ULL) + (b2 != ~0ULL));
+    m.ratio_pass = (uint8_t)(m.nfound == 2 && (float)m.d0 < ratio * (float)m.d1);
+    m.reserved[0] = m.reserved[1] = 0;
+    out[qi] = m;
+}
+
+int slamfe_match_plan(int nq_max, int nt_max, int npairs, int kernel, int* qpt, int* chunk_rows,
+                      int* nchunks)
+{
+    if (npairs < 1) npairs = 1;
+    long long qblocks = (nq_max + 255) / 256;
+    if (qblocks < 1) qblocks = 1;
+    const long long have = qblocks * npairs;
+    int rows, q;
+    if (kernel == SLAMFE_MATCH_MATRIX || (kernel == SLAMFE_MATCH_AUTO && nq_max >= 128)) {
+        // matrix-core kernel: a workgroup expands its 256 queries once (about the
+        // cost of three tiles), so chunks are long: 2048 rows for large train sets,
+        // 1024 for frame pairs (measured best on MI355X), less only when that
+        // would leave fewer than ~512 workgroups (a single frame pair)
+        q = 64;
+        rows = nt_max > 8192 ? 2048 : 1024;
+        while (rows > 256 && have * ((nt_max + rows - 1) / rows) < 512) rows >>= 1;
+    } else {
+        // few queries: the VALU kernel, one query row per lane.  Measured on MI355X:
+        // 256- or 512-row chunks beat 2 or 4 rows per lane by 7-13 %, and chunk
+        // sizes that are not a power of two ran up to 20 % slower.
+        q = 1;
+        rows = 256;
+        if (have * ((nt_max + 255) / 256) < 1024) rows = 128;
+        else if (have * ((nt_max + 511) / 512) >= 8192) rows = 512;
+    }
+    int nc = (nt_max + rows - 1) / rows;
+    if (nc < 1) nc = 1;
+    *qpt = q;
+    *chunk_rows = rows;
+    *nchunks = nc;
+    return 0;
+}
+
+int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int32_t* d_nq,
+                        const uint8_t* d_train, int nt, const int32_t* d_nt, int cap, int qpt,
+                        int chunk_rows, int nchunks, uint32_t* part, float ratio,
+                        slamfe_match2* d_out, uint64_t* d_keys, int64_t train_base, int npairs,
+                        int q_slot_base, int t_slot_base, int nslots)
+{
+    int nq_grid = d_nq ? cap : nq;
+    if (nq_grid <= 0 || npairs <= 0) return 0;
+    slamfe_pair_slots ps = {q_slot_base, t_slot_base, nslots};
+    const bool wide = nchunks > 32; // many chunks: wave-per-query merge, query-major partials
+    slamfe_match_geo mg;
+    mg.cap = cap;
+    mg.chunk_rows = chunk_rows;
+    mg.nchunks = nchunks;
+    mg.npairs = npairs;
+    mg.part_sq = wide ? nchunks : 1;
+    mg.part_sc = wide ? 1 : cap;
+    int qblocks = (nq_grid + 255) / 256; // both kernels: 256 queries per workgroup
+    dim3 grid((unsigned)qblocks * (unsigned)nchunks * (unsigned)npairs);
+    const uint32_t* q32 = reinterpret_cast<const uint32_t*>(d_query);
+    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(d_train);
+    if (qpt == 64)
+        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
+    else if (qpt == 1)
+        hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
+    else
+        return (int)hipErrorInvalidValue;
+    LAUNCH_CHECK();
+    if (wide)
+        hipLaunchKernelGGL(k_match_merge<64>, dim3((nq_grid + 3) / 4, npairs), dim3(256), 0, s, part, nq,
+                           d_nq, d_nt, nt, ratio, d_out, d_keys, train_base, ps, mg);
+    else
+        hipLaunchKernelGGL(k_match_merge<1>, dim3((nq_grid + 255) / 256, npairs), dim3(256), 0, s, part,
+                           nq, d_nq, d_nt, nt, ratio, d_out, d_keys, train_base, ps, mg);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int nshards, int nq,
+                                   float ratio, slamfe_match2* d_out)
+{
+    if (nq <= 0) return 0;
+    hipLaunchKernelGGL(k_merge_shard_keys, dim3((nq + 255) / 256), dim3(256), 0, s, d_keys, nshards,
+                       nq, ratio, d_out);
+    LAUNCH_CHECK();
+    return 0;
+}
