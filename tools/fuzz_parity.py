@@ -52,9 +52,31 @@ def main():
                 want = O.search_by_projection(f.pt, f.descriptors, kp_idx, muv, mdesc,
                                               np.arange(npts, dtype=np.int32), radius=radius)
                 oks = np.array_equal(got, want)
-        if not (ok and okm and oks):
+            # frame ingest with resize, reprojection, triangulation
+            okx = True
+            if case % 3 == 0 and w >= 96 and h >= 96:
+                bgr = np.ascontiguousarray(np.stack([img, np.roll(img, 1, 1), np.roll(img, 2, 0)], axis=2))
+                fx, fy = float(rng.choice([0.99, 0.9, 0.75, 1.0])), float(rng.choice([0.99, 0.8, 1.0]))
+                with FrontEnd(max_width=w, max_height=h, map_capacity=8192, **kw) as fe2:
+                    f2, resized = fe2.extract_scaled_bgr(bgr, fx, fy)
+                    want_r = O.resize_linear_8u(bgr, fx, fy)
+                    k2, d2 = O.extract(params_of(fe2), want_r)
+                    okx = np.array_equal(resized, want_r) and len(f2) == len(k2) and \
+                        all(np.array_equal(f2.keypoints[n], k2[n]) for n in k2.dtype.names) and \
+                        np.array_equal(f2.descriptors, d2)
+                    npts = int(rng.integers(1, 8000))
+                    pose, K, xyz, th = synth.camera_scene(npts, w, h, case)
+                    fe2.map_put_xyz(np.arange(npts), xyz)
+                    uv, idx = fe2.reproject(pose, K, th, w, h, npts)
+                    wuv, widx = O.reproject(pose, K, xyz, th, w, h)
+                    okx = okx and np.array_equal(idx, widx) and np.array_equal(uv.view(np.uint32), wuv.view(np.uint32))
+                    P1, P2, p1, p2 = synth.two_view_scene(int(rng.integers(1, 3000)), w, h, case)
+                    okx = okx and np.array_equal(fe2.triangulate(P1, P2, p1, p2).view(np.uint32),
+                                                 O.triangulate(P1, P2, p1, p2).view(np.uint32))
+        if not (ok and okm and oks and okx):
             bad += 1
-            print("MISMATCH", case, w, h, kw, "extract", ok, "match", okm, (nq, nt), "search", oks, flush=True)
+            print("MISMATCH", case, w, h, kw, "extract", ok, "match", okm, (nq, nt), "search", oks,
+                  "ingest/reproject/triangulate", okx, flush=True)
         elif case % 10 == 0:
             print("case", case, "ok", len(kps), "keypoints", flush=True)
     print("done:", cases, "cases,", bad, "mismatches")
