@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <utility>
@@ -360,12 +361,24 @@ int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kp
             continue;
         }
         ncopy[(size_t)i] = n;
-        if (n > 0 && kps)
-            HIPCHK(c, hipMemcpyAsync(hk + (size_t)i * K, c->kps + (size_t)slots[i] * K,
-                                     (size_t)n * sizeof(slamfe_keypoint), hipMemcpyDeviceToHost, s));
-        if (n > 0 && desc)
-            HIPCHK(c, hipMemcpyAsync(hd + (size_t)i * K * 32, c->desc + (size_t)slots[i] * K * 32,
-                                     (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    }
+    // One strided transfer per run of consecutive slots (a batch occupies
+    // consecutive slots of the ring, so at most two runs) instead of two small
+    // transfers per frame: every frame of the run sends its first `most` rows.
+    for (int i0 = 0; i0 < nf;) {
+        int i1 = i0 + 1;
+        while (i1 < nf && slots[i1] == slots[i1 - 1] + 1) ++i1;
+        int most = 0;
+        for (int i = i0; i < i1; ++i) most = std::max(most, ncopy[(size_t)i]);
+        if (most > 0 && kps)
+            HIPCHK(c, hipMemcpy2DAsync(hk + (size_t)i0 * K, K * sizeof(slamfe_keypoint),
+                                       c->kps + (size_t)slots[i0] * K, K * sizeof(slamfe_keypoint),
+                                       (size_t)most * sizeof(slamfe_keypoint), (size_t)(i1 - i0),
+                                       hipMemcpyDeviceToHost, s));
+        if (most > 0 && desc)
+            HIPCHK(c, hipMemcpy2DAsync(hd + (size_t)i0 * K * 32, K * 32, c->desc + (size_t)slots[i0] * K * 32,
+                                       K * 32, (size_t)most * 32, (size_t)(i1 - i0), hipMemcpyDeviceToHost, s));
+        i0 = i1;
     }
     HIPCHK(c, hipStreamSynchronize(s));
     for (int i = 0; i < nf; ++i) {
@@ -557,14 +570,23 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
     if (rc) return rc;
     // the staging buffers may still feed the previous call's queued copies
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (!imgs[i]) return fail(c, SLAMFE_E_INVALID, "imgs[%d] is NULL", i);
-        uint8_t* dst = c->h_in + (size_t)i * fbytes;
-        if ((size_t)stride == row) memcpy(dst, imgs[i], fbytes);
-        else
-            for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * row, imgs[i] + (size_t)y * stride, row);
+    // frames go to the pinned buffer in groups of about 2 MiB; each group's
+    // transfer to the device is queued as soon as it is staged, so the DMA of one
+    // group runs while the host copies the next
+    const int group = (int)std::max<size_t>(1, ((size_t)2 << 20) / fbytes);
+    for (int i0 = 0; i0 < n; i0 += group) {
+        const int i1 = std::min(n, i0 + group);
+        for (int i = i0; i < i1; ++i) {
+            uint8_t* dst = c->h_in + (size_t)i * fbytes;
+            if ((size_t)stride == row) memcpy(dst, imgs[i], fbytes);
+            else
+                for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * row, imgs[i] + (size_t)y * stride, row);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->in_stage + (size_t)i0 * fbytes, c->h_in + (size_t)i0 * fbytes,
+                                 (size_t)(i1 - i0) * fbytes, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->in_stage, c->h_in, (size_t)n * fbytes, hipMemcpyHostToDevice, c->stream));
     std::vector<uint64_t> hd((size_t)n);
     rc = run_extract(c, c->in_stage, n, w, h, (int)row, fbytes, channels, hd.data());
     if (rc) return rc;

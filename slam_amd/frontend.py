@@ -122,8 +122,13 @@ class FrontEnd:
             if f.shape != f0.shape:
                 raise ValueError("all frames of a batch must have one shape")
         cap = self.max_keypoints
-        kps = np.zeros((n, cap), abi.KEYPOINT_DTYPE)
-        desc = np.zeros((n, cap, 32), np.uint8)
+        # the landing buffers are kept between calls: fresh ones would be paged
+        # in anew every batch, which costs more than the transfer itself
+        held = getattr(self, "_batch_out", None)
+        if held is None or held[0].shape[0] < n:
+            held = (np.empty((n, cap), abi.KEYPOINT_DTYPE), np.empty((n, cap, 32), np.uint8))
+            self._batch_out = held
+        kps, desc = held[0][:n], held[1][:n]
         counts = np.zeros(n, np.int32)
         handles = np.zeros(n, np.uint64)
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
