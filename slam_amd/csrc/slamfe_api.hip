@@ -201,7 +201,7 @@ void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
         quota[0] = INT32_MAX;
     }
     uint32_t off = 0;
-    int tiles = 0, bands = 0;
+    int tiles = 0, bands = 0, groups = 0;
     size_t ntaps = 0;
     for (int l = 0; l < nlevels; ++l) {
         slamfe_dev_level& L = g->lv[l];
@@ -219,6 +219,8 @@ void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
         L.tiles_y = (L.h + SLAMFE_TILE_H - 1) / SLAMFE_TILE_H;
         L.tile_base = tiles;
         L.band_base = bands;
+        L.group_base = groups;
+        groups += L.tiles_x * ((L.tiles_y + SLAMFE_FB_TILES - 1) / SLAMFE_FB_TILES);
         tiles += L.tiles_x * L.tiles_y;
         bands += L.tiles_y;
         // column taps are read four at a time: 4-entry alignment, zero padding
@@ -230,6 +232,7 @@ void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
     g->frame_bytes = off;
     g->total_tiles = tiles;
     g->total_bands = bands;
+    g->total_groups = groups;
     if (taps) {
         taps->assign(ntaps, 0u);
         for (int l = 1; l < nlevels; ++l) {

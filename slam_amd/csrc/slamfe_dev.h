@@ -13,6 +13,9 @@
 #define SLAMFE_TILE_W 64
 #define SLAMFE_TILE_H 16
 #define SLAMFE_TILE_CAND 256
+/* The FAST + blur kernel works on groups of vertically adjacent tiles (one
+ * workgroup per group): the 8 halo rows a tile needs are then shared. */
+#define SLAMFE_FB_TILES 2
 
 /* One pyramid level of one frame.  All frames of a batch share the geometry;
  * frame f, level l starts at pyr + f * frame_bytes + off. */
@@ -26,13 +29,14 @@ typedef struct slamfe_dev_level {
     int32_t band_base;   /* index of the level's first tile row ("band") */
     float scale;         /* level scale factor (1, 1.2, 1.44, ...) */
     uint32_t tap_x, tap_y; /* offsets (in uint32 entries) of the level's resize taps */
-    int32_t pad;
+    int32_t group_base;  /* index of the level's first tile group (SLAMFE_FB_TILES tile rows each) */
 } slamfe_dev_level;
 
 typedef struct slamfe_dev_geom {
     int32_t nlevels;
     int32_t total_tiles;
     int32_t total_bands;
+    int32_t total_groups;
     uint32_t frame_bytes; /* bytes of one frame's pyramid */
     slamfe_dev_level lv[SLAMFE_MAX_LEVELS];
 } slamfe_dev_geom;

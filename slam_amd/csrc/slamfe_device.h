@@ -33,6 +33,15 @@ __device__ __forceinline__ int find_level_by_tile(const slamfe_dev_geom& g, int 
     return l;
 }
 
+__device__ __forceinline__ int find_level_by_group(const slamfe_dev_geom& g, int t)
+{
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < SLAMFE_MAX_LEVELS; ++i)
+        if (i < g.nlevels && t >= g.lv[i].group_base) l = i;
+    return l;
+}
+
 __device__ __forceinline__ int find_level_by_band(const slamfe_dev_geom& g, int b)
 {
     int l = 0;

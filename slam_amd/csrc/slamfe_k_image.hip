@@ -226,9 +226,11 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
 //        (detector->detect, Init.cc:76, per level inside cv::ORB; and the
 //        GaussianBlur(7x7, 2) cv::ORB applies before describing, Init.cc:78.)
 //
-// One workgroup = one 64x16 tile of one level of one frame.  The tile plus a
-// 4-px halo is read from HBM once (aligned dwords, REFLECT_101 at the image
-// border) into LDS and feeds both computations:
+// One workgroup = one group of SLAMFE_FB_TILES vertically adjacent 64x16 tiles
+// of one level of one frame (the last group of a level may hold fewer rows; all
+// passes are trimmed to the rows that exist).  The group plus a 4-px halo is
+// read from HBM once (aligned dwords, REFLECT_101 at the image border) into LDS
+// and feeds both computations:
 //
 //  FAST   pass B: every pixel of the tile + 1-px ring gets the 4-point
 //                 pretest (any arc of 9 holds one pixel of each opposite pair,
@@ -240,46 +242,60 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
 //                 inside the ORB border go to the tile's candidate list and to
 //                 the level's score histogram
 //  blur   rows:   v_dot4_u32_u8 of byte windows cut out with v_alignbyte
-//                 (3.5 VALU ops per output), 16-bit sums to LDS
-//         cols:   v_dot2_u32_u16 per tap, round, saturate, 4 pixels per store
+//                 (3.5 VALU ops per output), 16-bit sums to LDS, two rows per word
+//         cols:   v_dot2_u32_u16 per pair of taps, round, saturate, 4 pixels per store
 // ---------------------------------------------------------------------------
 #define FL_W (TW + 32)         /* LDS tile row: image columns x0-16 .. x0+79, six 16-byte pieces */
 #define FL_WD (FL_W / 4)
 #define FL_X0 12               /* byte column of image column x0-4 (the first one that is used) */
-#define FL_H (TH + 8)          /* 24 rows: y0-4 .. y0+19 */
+#define GH (TH * SLAMFE_FB_TILES) /* rows of a tile group */
+#define FL_H (GH + 8)          /* rows y0-4 .. y0+GH+3 */
 #define FB_COLS (TW + 8)       /* used columns: x0-4 .. x0+67 = 18 dwords */
 #define FB_COLD (FB_COLS / 4)
-#define FS_W (TW + 2)          /* score tile: 66 x 18 */
-#define FS_H (TH + 2)
-#define FS_N (FS_W * FS_H)     /* 1188 */
-#define BR_H (TH + 6)          /* rows of blur row sums: 22 */
+#define FS_W (TW + 2)          /* score tile: 66 x (GH + 2) */
+#define FS_H (GH + 2)
+#define FS_N (FS_W * FS_H)
+#define BR_H (GH + 6)          /* rows of blur row sums */
+
+// atomicAdd on an LDS word issued by one lane.  (Written as the instruction
+// itself: the compiler rewrites an atomicAdd whose operand is wave-uniform into
+// a lane-count multiplication with a second election of a leader lane, a dozen
+// extra instructions per call in a loop that is bound by instruction issue.)
+__device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p, uint32_t v)
+{
+    uint32_t old;
+    uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)p;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(v) : "memory");
+    return old;
+}
 
 __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
 {
     // ring pixel offsets in the LDS tile (pitch FL_W)
     constexpr int R[16][2] = SLAMFE_FAST_RING_INIT;
     int v = c[0];
-    int d[16];
+    int r[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[R[k][0] + R[k][1] * FL_W];
-    // min / max over every arc of 9 contiguous ring pixels:
-    // arc(s) = d[s..s+8] = three runs of three
+    for (int k = 0; k < 16; ++k) r[k] = (int)c[R[k][0] + R[k][1] * FL_W];
+    // min / max of the ring values over every arc of 9 contiguous ring pixels:
+    // arc(s) = r[s..s+8] = three runs of three.  With d = v - r the score terms
+    // are max_s min(d) = v - min_s max(r) and max_s min(-d) = max_s min(r) - v.
     int mn3[16], mx3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        int a = d[k], b = d[(k + 1) & 15], e = d[(k + 2) & 15];
+        int a = r[k], b = r[(k + 1) & 15], e = r[(k + 2) & 15];
         mn3[k] = min(a, min(b, e));
         mx3[k] = max(a, max(b, e));
     }
-    int A = INT_MIN, Bn = INT_MAX;
+    int lo = INT_MAX, hi = INT_MIN;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         int mn9 = min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
         int mx9 = max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
-        A = max(A, mn9);   // ring darker than centre by at least A on some arc
-        Bn = min(Bn, mx9); // ring brighter than centre by at least -Bn on some arc
+        lo = min(lo, mx9); // some arc lies entirely at or below lo
+        hi = max(hi, mn9); // some arc lies entirely at or above hi
     }
-    int m = max(A, -Bn);
+    int m = max(v - lo, hi - v);
     // corner <=> some arc has all |d| > thr on one side; score = that margin - 1
     return m > thr ? m - 1 : 0;
 }
@@ -291,31 +307,31 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
 {
     __shared__ uint32_t tile32[FL_H * FL_WD];
     __shared__ uint32_t sc32[(FS_N + 3) / 4];
-    __shared__ uint32_t rows32[BR_H * TW / 2];
+    __shared__ uint32_t rows32[(BR_H + 1) / 2 * TW];
     __shared__ uint16_t pos[FS_N];
-    __shared__ uint32_t list[SLAMFE_TILE_CAND];
-    __shared__ uint32_t nlist, npos;
+    __shared__ uint32_t list[SLAMFE_FB_TILES * SLAMFE_TILE_CAND];
+    __shared__ uint32_t nlist[SLAMFE_FB_TILES], npos;
     const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
     uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
 
     const int t = wg_item(), f = wg_frame(), tid = threadIdx.x;
     if (f >= nframes) return;
-    const int l = find_level_by_tile(g, t);
+    const int l = find_level_by_group(g, t);
     const slamfe_dev_level L = g.lv[l];
-    const int tl = t - L.tile_base;
-    const int x0 = (tl % L.tiles_x) * TW, y0 = (tl / L.tiles_x) * TH;
+    const int tl = t - L.group_base;
+    const int tx = tl % L.tiles_x, ty0 = (tl / L.tiles_x) * SLAMFE_FB_TILES;
+    const int x0 = tx * TW, y0 = ty0 * TH;
+    const int nrows = min(GH, L.h - y0); // image rows of this group
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
 
-    if (tid == 0) {
-        nlist = 0;
-        npos = 0;
-    }
-    // ---- tile load: 24 rows x six aligned 16-byte pieces (columns x0-16 .. x0+79;
+    if (tid < SLAMFE_FB_TILES) nlist[tid] = 0;
+    if (tid == 0) npos = 0;
+    // ---- tile load: nrows + 8 rows x six aligned 16-byte pieces (columns x0-16 .. x0+79;
     // columns x0-4 .. x0+67 are used).  Rows reflect at the top / bottom border by
     // index; pieces outside the row are zero, bytes past w inside the row's
     // padding are don't-care until the fix-up below.
-    if (tid < FL_H * 6) {
-        int ly = tid / 6, pc = tid - ly * 6;
+    for (int i = tid; i < (nrows + 8) * 6; i += 256) {
+        int ly = i / 6, pc = i - ly * 6;
         int gy = reflect101(y0 - 4 + ly, L.h);
         int gx = x0 - 16 + 16 * pc;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             v = *reinterpret_cast<const uint4*>(img + (size_t)gy * L.pitch + gx);
         *reinterpret_cast<uint4*>(&tile32[ly * FL_WD + 4 * pc]) = v;
     }
-    for (int i = tid; i < (FS_N + 3) / 4; i += 256) sc32[i] = 0;
+    for (int i = tid; i < ((nrows + 2) * FS_W + 3) / 4; i += 256) sc32[i] = 0;
     __syncthreads();
     // REFLECT_101 at the left / right image border (the blur reads 3 px across
     // it): copy the mirrored bytes inside LDS.  Only border tiles take this.
@@ -331,8 +347,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         const bool left = x0 == 0, right = x0 + TW + 3 >= L.w;
         if (left || right) { // uniform per workgroup
             uint8_t* tb = reinterpret_cast<uint8_t*>(tile32);
-            if (tid < FL_H * 8) {
-                int ly = tid >> 3, k = tid & 7; // k 0..2: left side, 4..6: right side
+            for (int i = tid; i < (nrows + 8) * 8; i += 256) {
+                int ly = i >> 3, k = i & 7; // k 0..2: left side, 4..6: right side
                 if (left && k < 3) {
                     // column -(k+1) <- column k+1
                     tb[ly * FL_W + FL_X0 + 4 - (k + 1)] = tb[ly * FL_W + FL_X0 + 4 + (k + 1)];
@@ -351,21 +367,22 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     // lx = 8m .. 8m+7 of row ly = sy + 3.  Bytes are widened to 16-bit pairs
     // (pixels 0,2 and 1,3 of a dword) so that packed 16-bit min / max / sub
     // handle two pixels per operation; a negative difference flags a survivor.
-    // (162 tasks: three wave passes; with 4 pixels per task it took six.)
+    // (With 4 pixels per task the pass took twice as many wave passes.)
     {
         typedef short v2s __attribute__((ext_vector_type(2)));
         union pk { uint32_t u; v2s v; };
         const int blo = max(3, edge - 1);
         // tiles that lie entirely in the discarded border band skip FAST
-        const bool any_fast = x0 + TW + 1 > blo && x0 - 1 < L.w - blo && y0 + TH + 1 > blo &&
+        const bool any_fast = x0 + TW + 1 > blo && x0 - 1 < L.w - blo && y0 + nrows + 1 > blo &&
                               y0 - 1 < L.h - blo;
         const bool interior = x0 - 1 >= blo && x0 + TW <= L.w - blo - 1 && y0 - 1 >= blo &&
-                              y0 + TH <= L.h - blo - 1;
+                              y0 + nrows <= L.h - blo - 1;
         const v2s t2 = {(short)thr, (short)thr};
         // survivors among the 4 pixels of dword C (ring pixels: U above, D below,
-        // L3 / R3 three to the left / right), one flag bit per pixel
+        // L3 / R3 three to the left / right): bit 7 of byte j of the result is
+        // set iff pixel j survives (the other bits are undefined)
         auto pretest4 = [&](uint32_t C, uint32_t U, uint32_t D, uint32_t L3, uint32_t R3) -> uint32_t {
-            uint32_t flags = 0;
+            uint32_t neg[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 pk v, p0, p8, p4, p12;
@@ -386,24 +403,24 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                 pk r1, r2;
                 r1.v = (v.v + t2) - hi; // < 0  <=>  hi > v + t
                 r2.v = lo - (v.v - t2); // < 0  <=>  lo < v - t
-                uint32_t neg = (r1.u | r2.u) & 0x80008000u;
-                // pair element 0 -> pixel `half`, element 1 -> pixel 2 + half
-                flags |= ((neg >> 15) & 1u) << half;
-                flags |= (neg >> 31) << (2 + half);
+                neg[half] = r1.u | r2.u; // sign bits: element 0 -> pixel `half`, element 1 -> pixel 2 + half
             }
-            return flags;
+            // the high bytes of the four 16-bit results, in pixel order
+            return __builtin_amdgcn_perm(neg[1], neg[0], 0x07030501u);
         };
-        for (int i = tid; any_fast && i < FS_H * (FB_COLD / 2); i += 256) {
+        for (int i = tid; any_fast && i < (nrows + 2) * (FB_COLD / 2); i += 256) {
             int sy = i / (FB_COLD / 2), m = i - sy * (FB_COLD / 2);
             int ly = sy + 3;
             const uint32_t* row = &tile32[ly * FL_WD + FL_X0 / 4 + 2 * m];
             uint32_t C0 = row[0], C1 = row[1], Cp = row[-1], Cn = row[2];
             uint32_t U0 = row[-3 * FL_WD], U1 = row[-3 * FL_WD + 1];
             uint32_t D0 = row[3 * FL_WD], D1 = row[3 * FL_WD + 1];
-            uint32_t flags = pretest4(C0, U0, D0, __builtin_amdgcn_alignbyte(C0, Cp, 1),
-                                      __builtin_amdgcn_alignbyte(C1, C0, 3)) |
-                             pretest4(C1, U1, D1, __builtin_amdgcn_alignbyte(C1, C0, 1),
-                                      __builtin_amdgcn_alignbyte(Cn, C1, 3)) << 4;
+            // flag of pixel k of the task: bit 7 + 8k for k < 4, bit 6 + 8(k-4) for k >= 4
+#define PRE_BIT(k) ((k) < 4 ? 7 + 8 * (k) : 6 + 8 * ((k) - 4))
+            uint32_t flags = (pretest4(C0, U0, D0, __builtin_amdgcn_alignbyte(C0, Cp, 1),
+                                       __builtin_amdgcn_alignbyte(C1, C0, 3)) & 0x80808080u) |
+                             ((pretest4(C1, U1, D1, __builtin_amdgcn_alignbyte(C1, C0, 1),
+                                        __builtin_amdgcn_alignbyte(Cn, C1, 3)) & 0x80808080u) >> 1);
             // pixel k is a score position iff lx = 8m+k in [3, 68] and the image
             // position is inside the band that can still yield a keypoint:
             // keypoints outside [edge, w-edge) x [edge, h-edge) are discarded by
@@ -411,8 +428,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             // are needed on [lo, w-lo) x [lo, h-lo) with lo = max(3, edge-1)
             // (tiles whose score area lies inside that band need the column rule only)
             uint32_t valid;
-            if (interior) { // uniform
-                valid = m == 0 ? 0xf8u : (m == FB_COLD / 2 - 1 ? 0x1fu : 0xffu);
+            if (interior) { // uniform: pixels 3..7 of the first task, 0..4 of the last
+                valid = m == 0 ? 0xc0404040u : (m == FB_COLD / 2 - 1 ? 0x808080c0u : 0xc0c0c0c0u);
             } else {
                 int gy = y0 - 1 + sy, gxb = x0 - 4 + 8 * m;
                 int kmin = max(3 - 8 * m, blo - gxb), kmax = min(FS_W + 2 - 8 * m, L.w - blo - 1 - gxb);
@@ -420,6 +437,10 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                 kmax = min(kmax, 7);
                 valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
                             ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
+                // bit j of a nibble -> bit 7 + 8j (the four shifted copies of the
+                // nibble inside the product do not overlap)
+                valid = (((valid & 15u) * 0x10204080u) & 0x80808080u) |
+                        ((((valid >> 4) * 0x10204080u) & 0x80808080u) >> 1);
             }
             flags &= valid;
             // wave-level compaction: exclusive prefix of the per-lane counts
@@ -436,41 +457,48 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             const uint32_t rank = lane_rank(act);
             uint32_t base = 0;
             if (tot) { // wave-uniform
-                if (rank == 0) base = atomicAdd(&npos, tot);
+                if (rank == 0) base = lds_fetch_add(&npos, tot);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + pre;
                 int sbase = sy * FS_W + 8 * m - 3;
+                uint8_t* slot = reinterpret_cast<uint8_t*>(pos) + 2u * base;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (flags & (1u << k)) pos[base++] = (uint16_t)(sbase + k);
+                    if (flags & (1u << PRE_BIT(k))) {
+                        *reinterpret_cast<uint16_t*>(slot) = (uint16_t)(sbase + k);
+                        slot += 2;
+                    }
             }
+#undef PRE_BIT
         }
     }
 
-    // ---- blur row pass: task = (row r of 22, group k of 8) -> 8 sums
-    // (176 tasks: three wave passes)
+    // ---- blur row pass: task = (row pair j, dword c of 16) -> the 4 row sums of
+    // sum rows 2j and 2j+1 (tile rows 2j+1, 2j+2), stored as pairs
+    // (row 2j | row 2j+1 << 16) per column: the column pass then feeds both
+    // halves of v_dot2_u32_u16 with real data
     {
         const uint32_t KA = 18u | (34u << 8) | (49u << 16) | (55u << 24); // taps 0..3
         const uint32_t KB = 49u | (34u << 8) | (18u << 16);               // taps 4..6, 0
-        // the 4 sums of the dword whose window is (d0, d1, d2): output c = 4k+j reads
-        // bytes (j+1 .. j+7) of the 12-byte window
-        auto rows4 = [&](uint32_t d0, uint32_t d1, uint32_t d2) -> uint2 {
+        // the 4 sums of the dword whose window is (d0, d1, d2): output j reads
+        // bytes (j+1 .. j+7) of the 12-byte window; each sum is <= 257 * 255 = 65535
+        auto rows4 = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t* o) {
             uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0, false);
-            s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, s0, false);
+            o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, s0, false);
             uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0, false);
-            s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, s1, false);
+            o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, s1, false);
             uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0, false);
-            s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, s2, false);
+            o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, s2, false);
             uint32_t s3 = __builtin_amdgcn_udot4(d1, KA, 0, false);
-            s3 = __builtin_amdgcn_udot4(d2, KB, s3, false);
-            // sums are <= 257 * 255 = 65535: two per dword
-            return make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+            o[3] = __builtin_amdgcn_udot4(d2, KB, s3, false);
         };
-        for (int i = tid; i < BR_H * 8; i += 256) {
-            int r = i >> 3, k = i & 7;
-            const uint32_t* p = &tile32[(r + 1) * FL_WD + FL_X0 / 4 + 2 * k]; // columns x0-4+8k .. +15
-            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-            uint2 a = rows4(d0, d1, d2), c = rows4(d1, d2, d3);
-            *reinterpret_cast<uint4*>(&rows32[r * (TW / 2) + 4 * k]) = make_uint4(a.x, a.y, c.x, c.y);
+        for (int i = tid; i < ((nrows + 7) >> 1) * 16; i += 256) {
+            int j = i >> 4, c = i & 15;
+            const uint32_t* p = &tile32[(2 * j + 1) * FL_WD + FL_X0 / 4 + c]; // columns x0-4+4c .. +11
+            uint32_t a[4], b[4];
+            rows4(p[0], p[1], p[2], a);
+            rows4(p[FL_WD], p[FL_WD + 1], p[FL_WD + 2], b);
+            *reinterpret_cast<uint4*>(&rows32[j * TW + 4 * c]) =
+                make_uint4(a[0] | (b[0] << 16), a[1] | (b[1] << 16), a[2] | (b[2] << 16), a[3] | (b[3] << 16));
         }
     }
     __syncthreads();
@@ -483,35 +511,48 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         sc[i] = (uint8_t)fast_score_lds(&tile[(sy + 3) * FL_W + FL_X0 + sx + 3], thr);
     }
 
-    // ---- blur column pass: task = (row r of 16, group k of 16) -> 4 pixels
-    {
+    // ---- blur column pass: task = (output row pair q, group k of 16) -> 2 x 4
+    // pixels.  Output row 2q sums rows 2q .. 2q+6 = pairs q .. q+3 with taps
+    // (K0,K1)(K2,K3)(K4,K5)(K6,0); row 2q+1 the same pairs with (0,K0)(K1,K2)(K3,K4)(K5,K6).
+    for (int task = tid; task < ((nrows + 1) >> 1) * 16; task += 256) {
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        constexpr int K[7] = SLAMFE_GAUSS7_INIT;
-        int r = tid >> 4, k = tid & 15;
-        int gy = y0 + r, gx = x0 + 4 * k;
-        if (gy < L.h && gx < L.w) {
-            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        union pk { uint32_t u; us2 v; };
+        constexpr uint32_t K[7] = SLAMFE_GAUSS7_INIT;
+        constexpr uint32_t TE[4] = {K[0] | (K[1] << 16), K[2] | (K[3] << 16), K[4] | (K[5] << 16), K[6]};
+        constexpr uint32_t TO[4] = {K[0] << 16, K[1] | (K[2] << 16), K[3] | (K[4] << 16), K[5] | (K[6] << 16)};
+        int q = task >> 4, k = task & 15;
+        int gy = y0 + 2 * q, gx = x0 + 4 * k;
+        if (gx < L.w) {
+            // the accumulators start at the rounding constant of the final >> 16
+            uint32_t e[4] = {32768u, 32768u, 32768u, 32768u}, o[4] = {32768u, 32768u, 32768u, 32768u};
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                uint2 v = *reinterpret_cast<const uint2*>(&rows32[(r + i) * (TW / 2) + 2 * k]);
-                us2 lo, hi, klo, khi;
-                lo.x = (unsigned short)v.x; lo.y = (unsigned short)(v.x >> 16);
-                hi.x = (unsigned short)v.y; hi.y = (unsigned short)(v.y >> 16);
-                klo.x = (unsigned short)K[i]; klo.y = 0;
-                khi.x = 0; khi.y = (unsigned short)K[i];
-                a0 = __builtin_amdgcn_udot2(lo, klo, a0, false);
-                a1 = __builtin_amdgcn_udot2(lo, khi, a1, false);
-                a2 = __builtin_amdgcn_udot2(hi, klo, a2, false);
-                a3 = __builtin_amdgcn_udot2(hi, khi, a3, false);
+            for (int i = 0; i < 4; ++i) {
+                uint4 v = *reinterpret_cast<const uint4*>(&rows32[(q + i) * TW + 4 * k]);
+                const uint32_t col[4] = {v.x, v.y, v.z, v.w};
+                pk te, to;
+                te.u = TE[i];
+                to.u = TO[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pk d;
+                    d.u = col[c];
+                    e[c] = __builtin_amdgcn_udot2(d.v, te.v, e[c], false);
+                    o[c] = __builtin_amdgcn_udot2(d.v, to.v, o[c], false);
+                }
             }
-            a0 = min((a0 + 32768u) >> 16, 255u);
-            a1 = min((a1 + 32768u) >> 16, 255u);
-            a2 = min((a2 + 32768u) >> 16, 255u);
-            a3 = min((a3 + 32768u) >> 16, 255u);
+            // result = min(acc >> 16, 255) = byte 2 of min(acc, 0x00ffffff)
+            auto pack = [](const uint32_t* a) -> uint32_t {
+                uint32_t a0 = min(a[0], 0x00ffffffu), a1 = min(a[1], 0x00ffffffu);
+                uint32_t a2 = min(a[2], 0x00ffffffu), a3 = min(a[3], 0x00ffffffu);
+                uint32_t lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);
+                uint32_t hi = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
+                return lo | hi;
+            };
             uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off + (size_t)gy * L.pitch + gx;
             // rows are padded to a multiple of 64 bytes, so the dword store stays
             // inside the row even when it covers pixels beyond w
-            *reinterpret_cast<uint32_t*>(out) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+            *reinterpret_cast<uint32_t*>(out) = pack(e);
+            if (gy + 1 < L.h) *reinterpret_cast<uint32_t*>(out + L.pitch) = pack(o);
         }
     }
     __syncthreads();
@@ -521,22 +562,28 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         int i = pos[k];
         int s = sc[i];
         int sy = i / FS_W, sx = i - sy * FS_W;
-        if (s > 0 && sy >= 1 && sy <= TH && sx >= 1 && sx <= TW) {
+        if (s > 0 && sy >= 1 && sy <= nrows && sx >= 1 && sx <= TW) {
             const uint8_t* p = &sc[i];
             int m = max(max(max(p[-1], p[1]), max(p[-FS_W - 1], p[-FS_W])),
                         max(max(p[-FS_W + 1], p[FS_W - 1]), max(p[FS_W], p[FS_W + 1])));
             int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
             if (s > m && gx >= edge && gx < L.w - edge && gy >= edge && gy < L.h - edge) {
-                uint32_t q = atomicAdd(&nlist, 1u);
-                list[q] = SLAMFE_KEY(gx, gy, s);
+                const int part = (sy - 1) / TH; // the tile of the group
+                uint32_t q = atomicAdd(&nlist[part], 1u);
+                list[part * SLAMFE_TILE_CAND + q] = SLAMFE_KEY(gx, gy, s);
             }
         }
     }
     __syncthreads();
-    const uint32_t n = nlist;
-    size_t tg = (size_t)f * g.total_tiles + t;
-    if (tid < n) cand[tg * SLAMFE_TILE_CAND + tid] = list[tid];
-    if (tid == 0) cand_cnt[tg] = n;
+#pragma unroll
+    for (int part = 0; part < SLAMFE_FB_TILES; ++part) {
+        if (ty0 + part < L.tiles_y) { // uniform
+            const uint32_t n = nlist[part];
+            size_t tg = (size_t)f * g.total_tiles + L.tile_base + (size_t)(ty0 + part) * L.tiles_x + tx;
+            if (tid < n) cand[tg * SLAMFE_TILE_CAND + tid] = list[part * SLAMFE_TILE_CAND + tid];
+            if (tid == 0) cand_cnt[tg] = n;
+        }
+    }
 }
 
 int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int stride,
@@ -577,7 +624,7 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
                             uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt)
 {
-    hipLaunchKernelGGL(k_fast_blur, frame_grid(g.total_tiles, nframes), dim3(256), 0, s, g, pyr, blur,
+    hipLaunchKernelGGL(k_fast_blur, frame_grid(g.total_groups, nframes), dim3(256), 0, s, g, pyr, blur,
                        nframes, thr, edge, cand, cand_cnt);
     LAUNCH_CHECK();
     return 0;
