@@ -446,7 +446,9 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             // wave-level compaction: exclusive prefix of the per-lane counts
             // (0..8) from four ballots, one LDS atomic per wave.  (A per-lane
             // atomicAdd of the count is turned by the compiler into a serial
-            // loop over the lanes and made the kernel 12 % slower.)
+            // loop over the lanes and made the kernel 12 % slower; one ballot per
+            // pixel with rank-addressed stores has a quarter fewer vector
+            // instructions but eight exec-mask sections and ran 6 % slower.)
             const uint32_t c = (uint32_t)__popc(flags);
             const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u),
                                      m3 = __ballot(c & 8u);

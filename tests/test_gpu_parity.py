@@ -202,6 +202,7 @@ def test_extract_and_match_large_batches(nframes):
             assert_frame_equal(f, kps, desc)
         cap = fe.max_keypoints
         out = torch.zeros((nframes - 1, cap, 16), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
         fe.match_resident_batch(got[1].handle, got[0].handle, nframes - 1, out.data_ptr())
         fe.sync()
         rows = out.cpu().numpy()
@@ -364,13 +365,13 @@ def test_match_sharded_keys_merge_equals_single(fe_orb):
     dq = torch.from_numpy(q).cuda()
     dt = torch.from_numpy(t).cuda()
     keys = torch.empty((shards, nq, 2), dtype=torch.int64, device="cuda")
+    out = torch.zeros(nq * 16, dtype=torch.uint8, device="cuda")
     bounds = [0, 1000, 1001, 3500, nt]  # uneven shards, one with a single row
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
     for s in range(shards):
         lo, hi = bounds[s], bounds[s + 1]
         fe_orb.match_shard_keys(dq.data_ptr(), nq, dt[lo:hi].data_ptr(), hi - lo, lo,
                                 keys[s].data_ptr())
-    out = torch.zeros(nq * 16, dtype=torch.uint8, device="cuda")
     fe_orb.merge_shard_keys(keys.data_ptr(), shards, nq, out.data_ptr())
     fe_orb.sync()
     got = out.cpu().numpy().view(abi.MATCH2_DTYPE)
