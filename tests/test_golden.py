@@ -127,3 +127,16 @@ def test_cxx_host_adapter_against_checker(tmp_path):
     r = subprocess.run([exe, str(pa), str(pb), "640", "480"], capture_output=True, timeout=110)
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
     assert b"host adapter ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_caller_of_batch_entry_points():
+    # tests/cpp/abi_batch_check.c: batch, per-frame, download and match calls agree
+    # bit for bit and the error paths answer as the header documents
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "abi_batch_check")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, timeout=110)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert b"abi batch check ok" in r.stdout
