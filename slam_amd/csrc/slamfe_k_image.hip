@@ -257,10 +257,11 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
 #define FS_N (FS_W * FS_H)
 #define BR_H (GH + 6)          /* rows of blur row sums */
 
-// atomicAdd on an LDS word issued by one lane.  (Written as the instruction
-// itself: the compiler rewrites an atomicAdd whose operand is wave-uniform into
-// a lane-count multiplication with a second election of a leader lane, a dozen
-// extra instructions per call in a loop that is bound by instruction issue.)
+// atomicAdd on an LDS word, written as the instruction itself: the compiler
+// rewrites atomicAdd into a scan over the lanes (per-lane operands) or a
+// lane-count multiplication with an election of a leader lane (uniform operand),
+// both costly in a loop that is bound by instruction issue.  The hardware
+// serialises the lanes that hit one address inside the LDS unit instead.
 __device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p, uint32_t v)
 {
     uint32_t old;
@@ -443,24 +444,18 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                         ((((valid >> 4) * 0x10204080u) & 0x80808080u) >> 1);
             }
             flags &= valid;
-            // wave-level compaction: exclusive prefix of the per-lane counts
-            // (0..8) from four ballots, one LDS atomic per wave.  (A per-lane
-            // atomicAdd of the count is turned by the compiler into a serial
-            // loop over the lanes and made the kernel 12 % slower; one ballot per
-            // pixel with rank-addressed stores has a quarter fewer vector
-            // instructions but eight exec-mask sections and ran 6 % slower.)
+            // compaction: every lane with survivors reserves its entries with one
+            // LDS atomic, issued as the instruction itself (see lds_fetch_add; the
+            // compiler's rewrite of atomicAdd with per-lane operands is a serial
+            // loop over the lanes that made the kernel 12 % slower).  Two
+            // wave-level schemes measured no better: an exclusive prefix of the
+            // lane counts from four count-bit ballots with one atomic per wave
+            // (same time, twice the code), and one ballot per pixel with
+            // rank-addressed stores (fewer vector instructions, eight exec-mask
+            // sections, 6 % slower).
             const uint32_t c = (uint32_t)__popc(flags);
-            const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u),
-                                     m3 = __ballot(c & 8u);
-            const unsigned long long act = __ballot(1);
-            uint32_t pre = lane_rank(m0) + 2u * lane_rank(m1) + 4u * lane_rank(m2) + 8u * lane_rank(m3);
-            const uint32_t tot = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) +
-                                 4u * (uint32_t)__popcll(m2) + 8u * (uint32_t)__popcll(m3);
-            const uint32_t rank = lane_rank(act);
-            uint32_t base = 0;
-            if (tot) { // wave-uniform
-                if (rank == 0) base = lds_fetch_add(&npos, tot);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + pre;
+            if (c) {
+                uint32_t base = lds_fetch_add(&npos, c);
                 int sbase = sy * FS_W + 8 * m - 3;
                 uint8_t* slot = reinterpret_cast<uint8_t*>(pos) + 2u * base;
 #pragma unroll
