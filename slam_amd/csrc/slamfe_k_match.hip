@@ -160,11 +160,15 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 //   sum_k a_k * b'_k = popcount(a) - 2 a.b = hamming(a, b) - popcount(b),
 // so one v_mfma_i32_32x32x32_i8 chain over the 256 bit positions (8 MFMAs) gives
 // the exact distances of 32 train rows x 32 queries, minus a per-query constant
-// that does not change the order.  In the result tile the query is the lane
-// (column) and the 16 registers are train rows, so the running top-2 of a query
-// stays in its lane: key = (dot + 256) << 22 | row-in-tile, one v_lshl_add per
-// distance, then v_min / v_med3 as in the VALU kernel.  Per comparison that is 3
-// VALU operations instead of 19; the 8 MFMAs of a tile take 256 cycles per SIMD.
+// that does not change the order.  The operands are stored scaled, train bits as
+// {0, 64} and query bits as {+64, -64}, so the chain delivers the distance times
+// 4096 = shifted left by 12, and the chain's initial accumulator holds
+// (256 << 12) + bias + row-in-tile per result register: the MFMA result IS the
+// key (distance << 12 | row), no instruction builds it.  In the result tile the
+// query is the lane (column) and the 16 registers are train rows, so the running
+// top-2 of a query stays in its lane: v_min / v_med3 per key as in the VALU
+// kernel, 2 VALU operations per comparison instead of 19; the 8 MFMAs of a tile
+// take 256 cycles per SIMD.
 //
 // A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to +-1 bytes in
 // 64 VGPRs per lane) x one chunk of train rows.  Train rows are read packed
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 #define MM_TILE 32
 #define MM_SUB 2 /* tiles per LDS stage (one workgroup barrier per stage) */
 #define MM_ROW 272
-#define MM_BIAS 8192u
-#define MM_SHIFT 22
+#define MM_BIAS 2048u /* >= 32 * (tiles per chunk - 1), < 4096 - 31: chunks of at most 2080 rows */
+#define MM_SHIFT 12
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
 
@@ -186,6 +190,11 @@ typedef int mm_v16i __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x, int pos)
 {
     return (((x >> pos) & 0xFu) * 0x00204081u) & 0x01010101u;
+}
+// the same with 64 for a set bit
+__device__ __forceinline__ uint32_t bits4_to_bytes64(uint32_t x, int pos)
+{
+    return (((x >> pos) & 0xFu) * 0x08102040u) & 0x40404040u;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_match_mfma(const uint32_t* __restrict__ query, int nq_imm,
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const uint32_t t = bits4_to_bytes(half, 4 * n);
-                B[blk][kb][n] = (int)(((t << 8) - t) | 0x01010101u); // bit 1 -> 0xff (-1), bit 0 -> 0x01
+                B[blk][kb][n] = (int)((((t << 8) - t) & 0x80808080u) | 0x40404040u); // bit 1 -> 0xc0 (-64), bit 0 -> 0x40 (+64)
             }
         }
         pq[blk] = pc;
@@ -260,10 +269,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
     auto store_tile = [&](int buf, int u, uint32_t bits) {
         uint4 a, b;
-        a.x = bits4_to_bytes(bits, 0);  a.y = bits4_to_bytes(bits, 4);
-        a.z = bits4_to_bytes(bits, 8);  a.w = bits4_to_bytes(bits, 12);
-        b.x = bits4_to_bytes(bits, 16); b.y = bits4_to_bytes(bits, 20);
-        b.z = bits4_to_bytes(bits, 24); b.w = bits4_to_bytes(bits, 28);
+        a.x = bits4_to_bytes64(bits, 0);  a.y = bits4_to_bytes64(bits, 4);
+        a.z = bits4_to_bytes64(bits, 8);  a.w = bits4_to_bytes64(bits, 12);
+        b.x = bits4_to_bytes64(bits, 16); b.y = bits4_to_bytes64(bits, 20);
+        b.z = bits4_to_bytes64(bits, 24); b.w = bits4_to_bytes64(bits, 28);
         uint4* d = reinterpret_cast<uint4*>(&sA[buf][u][(tid >> 3) * MM_ROW + (tid & 7) * 32]);
         d[0] = a;
         d[1] = b;
@@ -275,9 +284,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
 
     // result register j of lane half h is train row (j & 3) + 8 (j >> 2) + 4 h of the tile
-    uint32_t cj[16];
+    // and the accumulators start from (256 << MM_SHIFT) + MM_BIAS + that row, so
+    // that the MFMA chain delivers the finished keys
+    mm_v16i cj;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) cj[j] = (256u << MM_SHIFT) + MM_BIAS + (uint32_t)((j & 3) + 8 * (j >> 2) + 4 * h);
+    for (int j = 0; j < 16; ++j) cj[j] = (int)((256u << MM_SHIFT) + MM_BIAS + (uint32_t)((j & 3) + 8 * (j >> 2) + 4 * h));
     uint32_t b1[2] = {0xffffffffu, 0xffffffffu}, b2[2] = {0xffffffffu, 0xffffffffu};
 
     for (int st = 0; st < nstages; ++st) {
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int t = st * MM_SUB + u;
             if (t >= ntiles) break; // uniform
             const uint8_t* base = &sA[st & 1][u][r * MM_ROW + h * 16];
-            mm_v16i acc0 = {0}, acc1 = {0};
+            mm_v16i acc0 = cj, acc1 = cj;
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
                 const mm_v4i a = *reinterpret_cast<const mm_v4i*>(base + kb * 32);
@@ -302,8 +313,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (rows >= MM_TILE) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    uint32_t k0 = ((uint32_t)acc0[j] << MM_SHIFT) + cj[j];
-                    uint32_t k1 = ((uint32_t)acc1[j] << MM_SHIFT) + cj[j];
+                    uint32_t k0 = (uint32_t)acc0[j];
+                    uint32_t k1 = (uint32_t)acc1[j];
                     uint32_t n0, n1;
                     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
                     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
@@ -314,8 +325,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const bool ok = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
-                    uint32_t k0 = ok ? ((uint32_t)acc0[j] << MM_SHIFT) + cj[j] : 0xffffffffu;
-                    uint32_t k1 = ok ? ((uint32_t)acc1[j] << MM_SHIFT) + cj[j] : 0xffffffffu;
+                    uint32_t k0 = ok ? (uint32_t)acc0[j] : 0xffffffffu;
+                    uint32_t k1 = ok ? (uint32_t)acc1[j] : 0xffffffffu;
                     uint32_t n0, n1;
                     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
                     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
