@@ -170,13 +170,23 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 // kernel, 2 VALU operations per comparison instead of 19; the 8 MFMAs of a tile
 // take 256 cycles per SIMD.
 //
-// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to +-1 bytes in
+// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to +-64 bytes in
 // 64 VGPRs per lane) x one chunk of train rows.  Train rows are read packed
-// (32 bytes), expanded to 0/1 bytes into LDS (one dword -> 32 bytes per thread
+// (32 bytes), expanded to 0/64 bytes into LDS (one dword -> 32 bytes per thread
 // and tile, rows padded to 272 bytes so that the 16-byte fragment reads are
-// conflict-free), double-buffered.  Row indices inside the keys are relative to
-// the current tile (older entries are moved down by 32 per tile: 2 operations
-// per tile instead of re-basing 16 constants) and made absolute at the end.
+// conflict-free), double-buffered in stages of two tiles.  A stage is one block
+// of straight-line code: the 16 fragment reads of both tiles are issued first,
+// then the chains of tile t run while the vector ALU updates the top-2 from tile
+// t-1 (two accumulator sets) and expands the next stage's rows; 2 waves per SIMD
+// (242 VGPRs).  Row indices inside the keys are relative to the current tile
+// (older entries are moved down by 32 per tile: 2 operations per tile instead of
+// re-basing 16 constants) and made absolute at the end.
+//
+// Measured on MI355X (tools/ubench_mfma.hip, tools/time_match.py): the bare MFMA
+// chain with these operands runs at 4.9 POP/s (32.8 cycles per MFMA); the kernel
+// with chains only takes 0.28 ms for 2000 x 1M, fragment reads add 0.03, the top-2
+// update 0.04, expansion + barrier 0.10 -- they add up rather than overlap, and the
+// matrix pipes are busy 59 % of the kernel's cycles (SQ_VALU_MFMA_BUSY_CYCLES).
 // ---------------------------------------------------------------------------
 #define MM_TILE 32
 #define MM_SUB 2 /* tiles per LDS stage (one workgroup barrier per stage) */
@@ -185,6 +195,15 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 #define MM_SHIFT 12
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
+
+// Median of three, which the compiler turns into one v_med3_u32.  (Not inline
+// assembly: the compiler's hazard handling does not see a read of an MFMA result
+// inside an asm statement, and such a read issued too soon after the chain
+// returns the accumulator without the last products.)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return max(min(a, b), min(max(a, b), c));
+}
 
 // bits pos .. pos+3 of x -> four bytes of 0 / 1 (bit i in byte i)
 __device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x, int pos)
@@ -197,7 +216,7 @@ __device__ __forceinline__ uint32_t bits4_to_bytes64(uint32_t x, int pos)
     return (((x >> pos) & 0xFu) * 0x08102040u) & 0x40404040u;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_match_mfma(const uint32_t* __restrict__ query, int nq_imm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_match_mfma(const uint32_t* __restrict__ query, int nq_imm,
                                                     const int32_t* __restrict__ nq_dev,
                                                     const uint32_t* __restrict__ train, int nt_imm,
                                                     const int32_t* __restrict__ nt_dev,
@@ -264,8 +283,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // a stage = MM_SUB tiles; the thread's piece of tile u of a stage: dword
     // (tid & 7) of row (tid >> 3)
     auto load_bits = [&](int st, int u) -> uint32_t {
+        // (no branch: the row is clamped and the value discarded past the chunk)
         const int row = j0 + (st * MM_SUB + u) * MM_TILE + (tid >> 3);
-        return row < j1 ? train[(size_t)row * 8 + (tid & 7)] : 0u;
+        const uint32_t v = train[(size_t)min(row, j1 - 1) * 8 + (tid & 7)];
+        return row < j1 ? v : 0u;
     };
     auto store_tile = [&](int buf, int u, uint32_t bits) {
         uint4 a, b;
@@ -291,55 +312,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int j = 0; j < 16; ++j) cj[j] = (int)((256u << MM_SHIFT) + MM_BIAS + (uint32_t)((j & 3) + 8 * (j >> 2) + 4 * h));
     uint32_t b1[2] = {0xffffffffu, 0xffffffffu}, b2[2] = {0xffffffffu, 0xffffffffu};
 
-    for (int st = 0; st < nstages; ++st) {
+    // One tile's fragment reads (8 x 16 bytes per lane) and MFMA chains (two query
+    // blocks).  The reads of a tile are issued a whole tile ahead of the chains
+    // that consume them, so their LDS latency hides under the previous chains.
+    auto fetch = [&](int buf, int u, mm_v4i* a) {
+        const uint8_t* base = &sA[buf][u][r * MM_ROW + h * 16];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) a[kb] = *reinterpret_cast<const mm_v4i*>(base + kb * 32);
+    };
+    auto compute = [&](const mm_v4i* a, mm_v16i& acc0, mm_v16i& acc1) {
+        acc0 = cj;
+        acc1 = cj;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], B[0][kb], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], B[1][kb], acc1, 0, 0, 0);
+        }
+    };
+    // ... and the top-2 update from a finished tile's keys.  The two are issued
+    // for different tiles: the update of tile t runs on the vector ALU while the
+    // matrix core works on tile t+1 (two accumulator sets).
+    auto extract = [&](const mm_v16i& acc0, const mm_v16i& acc1, int rows) {
+        // entries of earlier tiles move down by one tile
+        b1[0] -= MM_TILE; b2[0] -= MM_TILE; b1[1] -= MM_TILE; b2[1] -= MM_TILE;
+        if (rows >= MM_TILE) { // uniform; only the last tile of a chunk can be short
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t k0 = (uint32_t)acc0[j];
+                uint32_t k1 = (uint32_t)acc1[j];
+                uint32_t n0, n1;
+                n0 = umed3(k0, b1[0], b2[0]);
+                n1 = umed3(k1, b1[1], b2[1]);
+                b1[0] = min(k0, b1[0]); b2[0] = n0;
+                b1[1] = min(k1, b1[1]); b2[1] = n1;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
+                uint32_t k0 = ok ? (uint32_t)acc0[j] : 0xffffffffu;
+                uint32_t k1 = ok ? (uint32_t)acc1[j] : 0xffffffffu;
+                uint32_t n0, n1;
+                n0 = umed3(k0, b1[0], b2[0]);
+                n1 = umed3(k1, b1[1], b2[1]);
+                b1[0] = min(k0, b1[0]); b2[0] = n0;
+                b1[1] = min(k1, b1[1]); b2[1] = n1;
+            }
+        }
+    };
+    static_assert(MM_SUB == 2, "the stage loop below is written for two tiles per stage");
+    const int last_rows = j1 - (j0 + (ntiles - 1) * MM_TILE); // valid rows of the last tile
+    mm_v16i P0, P1, Q0, Q1; // even tiles accumulate in P, odd tiles in Q
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Q0[j] = Q1[j] = -1;
+    // All stages but the last are straight-line code (both tiles full, a next stage
+    // to load): fragment reads, the two tiles' chains, the updates of the tiles
+    // before them and the expansion of the next stage's rows share one block that
+    // the compiler interleaves.  The last stage handles a short or missing tile.
+    mm_v4i F[8], G[8];
+    for (int st = 0; st + 1 < nstages; ++st) {
         uint32_t nbits[MM_SUB];
 #pragma unroll
-        for (int u = 0; u < MM_SUB; ++u) nbits[u] = st + 1 < nstages ? load_bits(st + 1, u) : 0u;
+        for (int u = 0; u < MM_SUB; ++u) nbits[u] = load_bits(st + 1, u);
+        fetch(st & 1, 0, F);
+        // the second tile's fragments are on their way while the first tile's chains run
+        fetch(st & 1, 1, G);
+        __builtin_amdgcn_sched_barrier(0); // keep the compiler from sinking the reads to their uses
+        compute(F, P0, P1);
+        // (in the first stage Q holds "no key" in every register and the update
+        // changes nothing)
+        extract(Q0, Q1, MM_TILE);
+        compute(G, Q0, Q1);
+        extract(P0, P1, MM_TILE);
 #pragma unroll
-        for (int u = 0; u < MM_SUB; ++u) {
-            const int t = st * MM_SUB + u;
-            if (t >= ntiles) break; // uniform
-            const uint8_t* base = &sA[st & 1][u][r * MM_ROW + h * 16];
-            mm_v16i acc0 = cj, acc1 = cj;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                const mm_v4i a = *reinterpret_cast<const mm_v4i*>(base + kb * 32);
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[0][kb], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[1][kb], acc1, 0, 0, 0);
-            }
-            // entries of earlier tiles move down by one tile
-            b1[0] -= MM_TILE; b2[0] -= MM_TILE; b1[1] -= MM_TILE; b2[1] -= MM_TILE;
-            const int rows = j1 - (j0 + t * MM_TILE); // valid rows of this tile (>= 32: all)
-            if (rows >= MM_TILE) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    uint32_t k0 = (uint32_t)acc0[j];
-                    uint32_t k1 = (uint32_t)acc1[j];
-                    uint32_t n0, n1;
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
-                    b1[0] = min(k0, b1[0]); b2[0] = n0;
-                    b1[1] = min(k1, b1[1]); b2[1] = n1;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const bool ok = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
-                    uint32_t k0 = ok ? (uint32_t)acc0[j] : 0xffffffffu;
-                    uint32_t k1 = ok ? (uint32_t)acc1[j] : 0xffffffffu;
-                    uint32_t n0, n1;
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n0) : "v"(k0), "v"(b1[0]), "v"(b2[0]));
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n1) : "v"(k1), "v"(b1[1]), "v"(b2[1]));
-                    b1[0] = min(k0, b1[0]); b2[0] = n0;
-                    b1[1] = min(k1, b1[1]); b2[1] = n1;
-                }
-            }
-        }
-        if (st + 1 < nstages) {
-#pragma unroll
-            for (int u = 0; u < MM_SUB; ++u) store_tile((st + 1) & 1, u, nbits[u]);
-        }
+        for (int u = 0; u < MM_SUB; ++u) store_tile((st + 1) & 1, u, nbits[u]);
         __syncthreads();
+    }
+    {
+        const int st = nstages - 1;
+        fetch(st & 1, 0, F);
+        fetch(st & 1, 1, G);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(F, P0, P1);
+        extract(Q0, Q1, MM_TILE);
+        if (st * MM_SUB + 1 < ntiles) { // uniform
+            compute(G, Q0, Q1);
+            extract(P0, P1, MM_TILE);
+            extract(Q0, Q1, last_rows);
+        } else {
+            extract(P0, P1, last_rows);
+        }
     }
 
     // the two lane halves hold disjoint train rows of the same query: merge, then
