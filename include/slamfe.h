@@ -110,7 +110,10 @@ typedef struct slamfe_ctx slamfe_ctx;
 /* Fill *p with the reference's constants (Init.cc:64-66, main.cc:11). */
 int slamfe_default_params(slamfe_params* p);
 
-/* Replaces the object construction of Init.cc:64-66. */
+/* Replaces the object construction of Init.cc:64-66.  On a device failure
+ * (SLAMFE_E_DEVICE: no GPU, out of device memory) *out may still receive a
+ * context: its only valid uses are slamfe_last_error and slamfe_destroy.  On
+ * SLAMFE_E_INVALID *out is NULL. */
 int slamfe_create(const slamfe_params* p, slamfe_ctx** out);
 /* Releases what slamfe_create made (the reference never frees the objects of
  * Init.cc:64-66; its process simply ends). */
