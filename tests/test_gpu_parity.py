@@ -601,3 +601,84 @@ def test_extract_checkerboard_ties(fe_orb):
     f = fe_orb.extract_keypoints(img) if True else None
     kps, desc = O.extract(oracle_params(fe_orb), img)
     assert_frame_equal(f, kps, desc)
+
+
+# ------------------------------------------- relocalisation at its full size
+def test_reloc_2000_by_1M_properties():
+    # 2000 queries against 1,000,000 map rows (2 * 10^9 comparisons): too many for
+    # the CPU checker, so the result is pinned by properties that do not depend on
+    # the size -- planted rows with known distances, the two independent kernels
+    # (matrix cores and vector-ALU popcount) agreeing bit for bit, the 8-way
+    # sharded merge equal to the single call, and a CPU check of the reported
+    # distances for a sample of queries.
+    import torch
+    from slam_amd.frontend import FrontEnd
+    NQ, NT, SH = 2000, 1_000_000, 8
+    train = synth.random_descriptors(NT, 3, 6)
+    query = synth.random_descriptors(NQ, 3, 5)
+    # plant: query i (i < 500) is train row p(i) with i % 20 bits flipped, and a
+    # second copy of that row with 21 + i % 5 flips sits at row q(i) > p(i)
+    rows = synth.rand_below(77, 1, np.arange(500), NT // 2 - 1)
+    rows2 = NT // 2 + synth.rand_below(77, 2, np.arange(500), NT // 2)
+    assert len(np.unique(rows)) + len(np.unique(rows2)) > 990
+    flips1 = np.arange(500) % 20
+    flips2 = 21 + np.arange(500) % 5
+    keep = np.ones(500, bool)
+    seen = set()
+    for i in range(500):
+        if rows[i] in seen or rows2[i] in seen:
+            keep[i] = False
+            continue
+        seen.add(int(rows[i]))
+        seen.add(int(rows2[i]))
+        bits = np.unpackbits(train[rows[i]], bitorder="little")
+        b1 = bits.copy()
+        pos = np.argsort(synth.hash_u64(79, 4, i * 256 + np.arange(256)))
+        b1[pos[:flips1[i]]] ^= 1
+        query[i] = np.packbits(b1, bitorder="little")
+        b2 = bits.copy()
+        b2[pos[40:40 + flips2[i]]] ^= 1
+        train[rows2[i]] = np.packbits(b2, bitorder="little")
+    dq = torch.from_numpy(query).cuda()
+    dt = torch.from_numpy(train).cuda()
+    outs = {}
+    for kern in (abi.MATCH_MATRIX, abi.MATCH_POPCOUNT):
+        keys = torch.empty((NQ, 2), dtype=torch.int64, device="cuda")
+        out = torch.zeros(NQ * 16, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        with FrontEnd(mode=abi.MODE_ORB, max_width=64, max_height=64, max_batch=1, map_capacity=0,
+                      match_kernel=kern) as fe:
+            fe.match_shard_keys(dq.data_ptr(), NQ, dt.data_ptr(), NT, 0, keys.data_ptr())
+            fe.merge_shard_keys(keys.data_ptr(), 1, NQ, out.data_ptr())
+            fe.sync()
+            outs[kern] = out.cpu().numpy().view(abi.MATCH2_DTYPE).copy()
+            if kern == abi.MATCH_MATRIX:
+                # the same job in 8 uneven shards, merged
+                keys8 = torch.empty((SH, NQ, 2), dtype=torch.int64, device="cuda")
+                out8 = torch.zeros(NQ * 16, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                bounds = [0, 1, 125_000, 250_001, 375_000, 500_000, 700_000, 999_999, NT]
+                for s in range(SH):
+                    lo, hi = bounds[s], bounds[s + 1]
+                    fe.match_shard_keys(dq.data_ptr(), NQ, dt[lo:hi].data_ptr(), hi - lo, lo,
+                                        keys8[s].data_ptr())
+                fe.merge_shard_keys(keys8.data_ptr(), SH, NQ, out8.data_ptr())
+                fe.sync()
+                sharded = out8.cpu().numpy().view(abi.MATCH2_DTYPE)
+    m, v = outs[abi.MATCH_MATRIX], outs[abi.MATCH_POPCOUNT]
+    for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+        assert np.array_equal(m[name], v[name]), name        # two kernels, one answer
+        assert np.array_equal(m[name], sharded[name]), name  # sharding does not change it
+    k = np.nonzero(keep)[0]
+    assert len(k) > 480
+    assert np.array_equal(m["idx0"][k], rows[k]) and np.array_equal(m["d0"][k], flips1[k])
+    # the second copy differs from the query in flips1 + flips2 bits (disjoint positions)
+    assert np.array_equal(m["idx1"][k], rows2[k]) and np.array_equal(m["d1"][k], (flips1 + flips2)[k])
+    assert np.all(m["ratio_pass"][k] == (4 * flips1[k] < 3 * (flips1 + flips2)[k]))
+    # the reported distances are the true distances to the reported rows
+    for i in list(range(500, 520)) + [1999]:
+        for idx, d in ((m["idx0"][i], m["d0"][i]), (m["idx1"][i], m["d1"][i])):
+            assert int(np.unpackbits(query[i] ^ train[idx]).sum()) == int(d)
+        assert m["d0"][i] <= m["d1"][i] and m["nfound"][i] == 2
+        # random 256-bit rows: the best of a million lies far below the mean of 128
+        assert 60 < m["d0"][i] < 100
