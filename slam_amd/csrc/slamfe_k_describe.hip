@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
 //     64+i, 128+i, 192+i, so each wave ballot is 8 descriptor bytes.
 // ---------------------------------------------------------------------------
 #define DP_ROWS 37 /* samples reach +-18 px (|pattern| <= 13 * sqrt 2 = 18.4) */
-#define DP_DW 10   /* 37 bytes from column cx-18, read as 10 dwords */
+#define DP_PC 3    /* 37 bytes from column cx-18, read as three 16-byte pieces */
+#define DP_PITCH (16 * DP_PC) /* bytes of a patch row in LDS */
 
 // A wavefront walks keypoints idx = wave, wave + nwaves, ...  For each one it
 // stages the 37-row neighbourhood (rows of 40 bytes starting at cx-18,
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   uint8_t* __restrict__ desc, int max_kp, int nframes)
 {
     typedef float v2f __attribute__((ext_vector_type(2)));
-    __shared__ uint32_t patch32[4][DP_ROWS * DP_DW];
+    __shared__ uint4 patch128[4][DP_ROWS * DP_PC];
     const int f = wg_frame();
     if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
@@ -185,16 +186,19 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
         P[j][1] = (v2f){(float)t[2], (float)t[2]};
         Q[j][1] = (v2f){(float)t[3], (float)t[3]};
     }
-    constexpr int NIT = (DP_ROWS * DP_DW + 63) / 64;
+    // The patch is fetched in 16-byte pieces (unaligned in memory): the kernel's
+    // time is the address unit's, which spends about as long on a wave's dword
+    // loads as on its 16-byte loads.
+    constexpr int NIT = (DP_ROWS * DP_PC + 63) / 64;
     int trow[NIT], tcol[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int t = it * 64 + lane, row = t / DP_DW;
+        const int t = it * 64 + lane, row = t / DP_PC;
         trow[it] = row < DP_ROWS ? row : 0;
-        tcol[it] = 4 * (t - row * DP_DW);
+        tcol[it] = 16 * (t - row * DP_PC);
     }
-    uint32_t* my = patch32[wv];
-    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * (DP_DW * 4) + 18;
+    uint4* my = patch128[wv];
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * DP_PITCH + 18;
     const uint8_t* frame = blur + (size_t)f * g.frame_bytes;
     const uint32_t* keys = kp_key + (size_t)slot * max_kp;
     const uint32_t* levels = kp_level + (size_t)slot * max_kp;
@@ -215,16 +219,18 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
         const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
         if (cx < 18 || cy < 18 || cx >= w - 22 || cy >= h - 18) continue; // reads must stay inside
         const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 18) * pitch + (cx - 18);
-        uint32_t r[NIT];
+        // (the last piece of a row reaches 8 bytes past the 40 that are used:
+        // into the row's padding or the next row, always inside the pyramid buffer)
+        uint4 r[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            r[it] = 0;
-            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_DW)
-                r[it] = load_u32_unaligned(base + trow[it] * pitch + tcol[it]);
+            r[it] = make_uint4(0, 0, 0, 0);
+            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC)
+                __builtin_memcpy(&r[it], base + trow[it] * pitch + tcol[it], 16);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
-            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_DW) my[it * 64 + lane] = r[it];
+            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC) my[it * 64 + lane] = r[it];
         // only this wavefront reads what it wrote: LDS operations of one wave are
         // ordered, the fences keep the compiler from moving accesses across
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                 v2f pt = P[j][e] * AB + Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
                 pt = pt + magic;
                 const int ix = (short)__float_as_int(pt.x), iy = (short)__float_as_int(pt.y);
-                v[e] = c[iy * (DP_DW * 4) + ix];
+                v[e] = c[iy * DP_PITCH + ix];
             }
             word[j] = __ballot(v[0] < v[1]);
         }
