@@ -39,11 +39,14 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
     if (wave >= n) return;
     // half-widths of the disc rows |v| = 0..15, one nibble each
     const unsigned long long umax = 0x3689abcddeeeffffULL;
+    // A lane owns one 16-byte half of one of the 31 patch rows (62 lanes): one
+    // 16-byte load per keypoint.  (With four dword loads per lane the address unit
+    // was the busiest part of the CU.)
     uint32_t wT[4], wV[4], wS[4];
-    int trow[4], tcol[4];
+    const int row = lane >> 1, half = lane & 1;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int t = it * 64 + lane, row = t >> 3, dw = t & 7;
+        const int dw = 4 * half + it;
         const int v = row - 15, av = v < 0 ? -v : v;
         const int d = row < 31 ? (int)((umax >> (4 * av)) & 15ULL) : -1;
         uint32_t a = 0, b = 0, c = 0;
@@ -59,9 +62,8 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
         wT[it] = a;
         wV[it] = b;
         wS[it] = c;
-        trow[it] = row < 31 ? row : 0;
-        tcol[it] = 4 * dw;
     }
+    const int trow = row < 31 ? row : 0, tcol = 16 * half;
     const uint8_t* frame = pyr + (size_t)f * g.frame_bytes;
     const uint32_t* keys = kp_key + (size_t)slot * max_kp;
     const uint32_t* levels = kp_level + (size_t)slot * max_kp;
@@ -79,13 +81,14 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
         if (cx < 16 || cy < 16 || cx >= w - 17 || cy >= h - 16) continue; // reads must stay inside
         const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 15) * pitch + (cx - 15);
         uint32_t T = 0, V = 0, S = 0;
+        uint4 x4 = make_uint4(0, 0, 0, 0);
+        if (lane < 62) __builtin_memcpy(&x4, base + trow * pitch + tcol, 16);
+        const uint32_t xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            uint32_t x = 0;
-            if (it < 3 || lane < 56) x = load_u32_unaligned(base + trow[it] * pitch + tcol[it]);
-            T = __builtin_amdgcn_udot4(x, wT[it], T, false);
-            V = __builtin_amdgcn_udot4(x, wV[it], V, false);
-            S = __builtin_amdgcn_udot4(x, wS[it], S, false);
+            T = __builtin_amdgcn_udot4(xs[it], wT[it], T, false);
+            V = __builtin_amdgcn_udot4(xs[it], wV[it], V, false);
+            S = __builtin_amdgcn_udot4(xs[it], wS[it], S, false);
         }
         const int m10 = wave_sum((int)T - 32 * (int)S);
         const int m01 = wave_sum((int)V - 16 * (int)S);
