@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed load before the warm-up steps so that the GPU clock has settled")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent frame streams per GPU, each with its own context and HIP stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -192,6 +194,15 @@ def main():
         return hd
 
     with torch.cuda.stream(stream):
+        # Untimed, before the W warm-up steps: keep the GPU under this load for a
+        # fraction of a second.  The chip raises its clock only after tens of
+        # milliseconds of work, and a short run (few steps of ~1.3 ms) would
+        # otherwise be timed partly at the idle clock.
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(dev)
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize(dev)
