@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256) void k_ingest_scaled(const uint8_t* __restrict
 // taps: ofs | c1 << 16 per destination column / row (host-computed in double).
 // A lane produces 4 adjacent pixels and stores them as one dword.  The source
 // bytes of a row come from three aligned dwords starting at (ofs[0] & ~3); the
-// two taps of each pixel are cut out with v_alignbyte, widened to a 16-bit pair
-// and combined with their 8.8 weights by v_dot2_u32_u16; the vertical blend of
+// two taps of each pixel are picked and widened to a 16-bit pair by one v_perm
+// (selector decoded once per column block) and combined with their 8.8 weights
+// by v_dot2_u32_u16; the vertical blend of
 // the two 8.8 row results is one more v_dot2 with the rounding constant as the
 // addend:  out = (h0*w0 + h1*w1 + 2^15) >> 16.
 // ---------------------------------------------------------------------------
@@ -147,15 +148,20 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
         const uint4 tx = *reinterpret_cast<const uint4*>(taps + D.tap_x + x);
         const uint32_t txs[4] = {tx.x, tx.y, tx.z, tx.w};
         const uint32_t a = (txs[0] & 0xffffu) & ~3u; // aligned start of the 12 source bytes
-        uint32_t sh[4], sel[4];
+        // per pixel: which dword pair of the 12-byte window holds its two taps
+        // (bytes o, o+1 with o = 0 .. 10: the pair (p0,p1) up to o = 6, else (p1,p2))
+        // and the v_perm selector that picks them widened to 16 bits each
+        bool upper[4];
+        uint32_t pick[4];
         slamfe_us2 cv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t o = (txs[k] & 0xffffu) - a; // 0 .. 10
             const uint32_t c1 = txs[k] >> 16;
             cv[k] = as_us2((256u - c1) | (c1 << 16));
-            sh[k] = o;
-            sel[k] = o >> 2;
+            upper[k] = o >= 7u;
+            const uint32_t off = upper[k] ? o - 4u : o;
+            pick[k] = 0x0c000c00u | ((off + 1u) << 16) | off; // 0x00 b(off+1) 0x00 b(off)
         }
         // horizontal pass of one source row: the 4 pixels' 8.8 values, two per dword.
         // 12 source bytes; bytes past the row end are read but carry weight 0
@@ -163,10 +169,8 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
             uint32_t h[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                uint32_t lo = sel[k] == 0 ? p0 : (sel[k] == 1 ? p1 : p2);
-                uint32_t hi = sel[k] == 0 ? p1 : (sel[k] == 1 ? p2 : 0u);
-                uint32_t q = __builtin_amdgcn_alignbyte(hi, lo, sh[k]); // bytes o, o+1 in bits 0..15
-                q = __builtin_amdgcn_perm(0u, q, 0x0c010c00u);          // widen: 0x00 b1 0x00 b0
+                const uint32_t lo = upper[k] ? p1 : p0, hi = upper[k] ? p2 : p1;
+                const uint32_t q = __builtin_amdgcn_perm(hi, lo, pick[k]);
                 h[k] = __builtin_amdgcn_udot2(as_us2(q), cv[k], 0u, false); // 8.8, <= 65280
             }
             return make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
@@ -197,12 +201,13 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
                 const uint32_t e1 = __builtin_amdgcn_perm(Hcur.x, H0.x, 0x07060302u); // px1: high halves
                 const uint32_t e2 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x05040100u);
                 const uint32_t e3 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x07060302u);
-                uint32_t v0 = __builtin_amdgcn_udot2(as_us2(e0), wv2, 1u << 15, false) >> 16;
-                uint32_t v1 = __builtin_amdgcn_udot2(as_us2(e1), wv2, 1u << 15, false) >> 16;
-                uint32_t v2 = __builtin_amdgcn_udot2(as_us2(e2), wv2, 1u << 15, false) >> 16;
-                uint32_t v3 = __builtin_amdgcn_udot2(as_us2(e3), wv2, 1u << 15, false) >> 16;
-                const uint32_t out = min(v0, 255u) | (min(v1, 255u) << 8) | (min(v2, 255u) << 16) |
-                                     (min(v3, 255u) << 24);
+                // each sum is at most 65280 * 256 + 2^15 < 2^24: its byte 2 is the pixel
+                const uint32_t v0 = __builtin_amdgcn_udot2(as_us2(e0), wv2, 1u << 15, false);
+                const uint32_t v1 = __builtin_amdgcn_udot2(as_us2(e1), wv2, 1u << 15, false);
+                const uint32_t v2 = __builtin_amdgcn_udot2(as_us2(e2), wv2, 1u << 15, false);
+                const uint32_t v3 = __builtin_amdgcn_udot2(as_us2(e3), wv2, 1u << 15, false);
+                const uint32_t out = __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u) |
+                                     __builtin_amdgcn_perm(v3, v2, 0x06020c0cu);
                 // rows are padded to a multiple of 64 bytes: the dword store stays in the row
                 *reinterpret_cast<uint32_t*>(dst + (size_t)y * dpitch + x) = out;
                 if (++y < y_end) {
