@@ -121,7 +121,13 @@ __device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
     return c.v;
 }
 
-// A wavefront produces RS_ROWS consecutive destination rows.  Everything that
+// A wavefront produces RS_ROWS consecutive destination rows of a block of 64
+// columns (16 lanes x 4 pixels) in four frames at once (lane / 16 = frame within
+// the group): level widths are nowhere near multiples of 256 columns, and with a
+// whole wave on one row 30 % of the lanes idled; the row walk stays wave-uniform
+// because the four frames share the geometry.  The frames of a group are 8 apart
+// so that they belong to the same XCD as in the other per-frame kernels.
+// Everything that
 // depends on the column only (source offset, byte selection, tap weights of the
 // lane's 4 pixels) is decoded once per column block; the horizontal pass of a
 // source row (4 values of 8.8 fixed point, two dwords) is computed once and used
@@ -136,14 +142,19 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
     const slamfe_dev_level& S = g.lv[l - 1];
     const slamfe_dev_level& D = g.lv[l];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int y_first = (wg_item() * 4 + wv) * RS_ROWS;
-    const int f = wg_frame();
-    if (f >= nframes || y_first >= D.h) return;
+    const int nxb = (D.w + 63) >> 6; // column blocks of the level
+    const int item = wg_item();
+    const int y_first = ((item / nxb) * 4 + wv) * RS_ROWS;
+    if (y_first >= D.h) return;
     const int y_end = min(y_first + RS_ROWS, D.h);
+    const int lane = threadIdx.x & 63;
+    // frame of this lane: group member j = lane / 16 of the group blockIdx.z
+    const int f = (int)((blockIdx.z * 4 + (unsigned)(lane >> 4)) * gridDim.x + blockIdx.x);
+    const int x = (item % nxb) * 64 + (lane & 15) * 4;
     const uint8_t* src = pyr + (size_t)f * g.frame_bytes + S.off;
     uint8_t* dst = pyr + (size_t)f * g.frame_bytes + D.off;
     const int spitch = S.pitch, dpitch = D.pitch;
-    for (int x = (threadIdx.x & 63) * 4; x < D.w; x += 256) {
+    if (f < nframes && x < D.w) {
         // the tap table is padded with zero entries to a multiple of 4 per level
         const uint4 tx = *reinterpret_cast<const uint4*>(taps + D.tap_x + x);
         const uint32_t txs[4] = {tx.x, tx.y, tx.z, tx.w};
@@ -183,13 +194,13 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
         uint32_t w1 = ty >> 16;
         int yo1 = yo + (w1 ? 1 : 0);
         int sy = yo;
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(src + (size_t)sy * spitch + a);
-        uint32_t p0 = r[0], p1 = r[1], p2 = r[2];
+        uint3 pw = *reinterpret_cast<const uint3*>(src + (size_t)sy * spitch + a);
+        uint32_t p0 = pw.x, p1 = pw.y, p2 = pw.z;
         uint2 Hprev = make_uint2(0, 0), Hcur = make_uint2(0, 0);
         while (y < y_end) { // uniform
             const int nsy = min(sy + 1, S.h - 1);
-            const uint32_t* rn = reinterpret_cast<const uint32_t*>(src + (size_t)nsy * spitch + a);
-            const uint32_t n0 = rn[0], n1 = rn[1], n2 = rn[2];
+            const uint3 nw = *reinterpret_cast<const uint3*>(src + (size_t)nsy * spitch + a);
+            const uint32_t n0 = nw.x, n1 = nw.y, n2 = nw.z;
             Hprev = Hcur;
             Hcur = hpass(p0, p1, p2);
             while (y < y_end && yo1 == sy) { // destination rows whose second source row is sy
@@ -616,8 +627,11 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
                           const uint32_t* taps)
 {
     for (int l = 1; l < g.nlevels; ++l) {
-        hipLaunchKernelGGL(k_resize, frame_grid((g.lv[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nframes), dim3(256), 0, s, g, l,
-                           nframes, pyr, taps);
+        // items = strips of 4 * RS_ROWS rows x blocks of 64 columns; a workgroup
+        // covers four frames of the grid's frame axis (see k_resize)
+        dim3 grid = frame_grid((g.lv[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS) * ((g.lv[l].w + 63) / 64), nframes);
+        grid.z = (grid.z + 3) / 4;
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, g, l, nframes, pyr, taps);
         LAUNCH_CHECK();
     }
     return 0;
