@@ -286,6 +286,16 @@ int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamf
 #define SLAMFE_STAGE_MATCH 7
 int slamfe_debug_time_stage(slamfe_ctx* ctx, int stage, int nframes, int reps, float* avg_ms);
 
+/* Measurement hook (no counterpart in the reference): the same stages timed where
+ * they run.  After slamfe_debug_probe(ctx, stage) every slamfe_extract_resident
+ * / _batch call (stages 1..6) or slamfe_match_resident_batch call (stage 7)
+ * records a pair of HIP events around that stage on the context's stream (the
+ * first 64 intervals are kept); slamfe_debug_probe_read waits for the stream and
+ * returns their mean in milliseconds and their number.  stage 0 switches the
+ * probe off. */
+int slamfe_debug_probe(slamfe_ctx* ctx, int stage);
+int slamfe_debug_probe_read(slamfe_ctx* ctx, float* avg_ms, int* n);
+
 /* Test hook (no counterpart in the reference): copy pyramid level `level` of
  * frame `frame_in_batch` of the most recent extraction to the host, either
  * the unblurred level (blurred = 0: what FAST and the orientation read) or the

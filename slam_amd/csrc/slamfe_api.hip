@@ -89,6 +89,11 @@ struct slamfe_ctx {
     Scratch rp_uv_all, rp_mask, rp_off, rp_total, vis_uv, vis_idx;
     Scratch tri_in, tri_out;
     int vis_count = -1;
+    // in-pipeline stage probe (slamfe_debug_probe): events around one stage of
+    // every extraction / batched match that is queued while the probe is set
+    int probe_stage = 0;
+    std::vector<hipEvent_t> probe_ev; // pairs: begin, end
+    size_t probe_used = 0;            // events recorded so far
 };
 
 namespace {
@@ -121,6 +126,22 @@ int fail(slamfe_ctx* c, int code, const char* fmt, ...)
             return fail((c), SLAMFE_E_DEVICE, "%s failed: %s", #call,                       \
                         hipGetErrorString((hipError_t)e_));                                 \
     } while (0)
+
+// Events around `stage` while the probe is set on it (at most 64 intervals are kept).
+struct ProbeScope {
+    slamfe_ctx* c;
+    bool on;
+    ProbeScope(slamfe_ctx* ctx, int stage) : c(ctx), on(false)
+    {
+        if (c->probe_stage != stage || c->probe_used + 2 > c->probe_ev.size()) return;
+        on = hipEventRecord(c->probe_ev[c->probe_used], c->stream) == hipSuccess;
+    }
+    ~ProbeScope()
+    {
+        if (!on) return;
+        if (hipEventRecord(c->probe_ev[c->probe_used + 1], c->stream) == hipSuccess) c->probe_used += 2;
+    }
+};
 
 int grow(slamfe_ctx* c, Scratch& s, size_t bytes)
 {
@@ -311,17 +332,32 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     if (d_imgs)
         KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
                                      g.frame_bytes, g.lv[0].pitch));
-    KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
-    KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
-                                    c->p.edge_threshold, c->cand, c->cand_cnt));
-    KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->band_hist, c->band_off, c->level_kept,
-                                 c->level_cutoff, slot_base, c->nslots, c->kp_key, c->kp_level,
-                                 c->kp_count, c->max_kp, c->sort_lds));
-    KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
-                                 c->kp_count, c->kp_mom, c->kps, c->kp_rot, c->max_kp, c->p.mode,
-                                 c->p.patch_size));
-    KCHK(c, slamfe_launch_describe(s, g, n, c->blur, slot_base, c->nslots, c->kp_key, c->kp_level,
-                                   c->kp_count, c->kp_rot, c->desc, c->max_kp));
+    {
+        ProbeScope ps(c, SLAMFE_STAGE_PYRAMID);
+        KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
+    }
+    {
+        ProbeScope ps(c, SLAMFE_STAGE_FAST);
+        KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
+                                        c->p.edge_threshold, c->cand, c->cand_cnt));
+    }
+    {
+        ProbeScope ps(c, SLAMFE_STAGE_SELECT);
+        KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->band_hist, c->band_off,
+                                     c->level_kept, c->level_cutoff, slot_base, c->nslots, c->kp_key,
+                                     c->kp_level, c->kp_count, c->max_kp, c->sort_lds));
+    }
+    {
+        ProbeScope ps(c, SLAMFE_STAGE_ORIENT);
+        KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
+                                     c->kp_count, c->kp_mom, c->kps, c->kp_rot, c->max_kp, c->p.mode,
+                                     c->p.patch_size));
+    }
+    {
+        ProbeScope ps(c, SLAMFE_STAGE_DESCRIBE);
+        KCHK(c, slamfe_launch_describe(s, g, n, c->blur, slot_base, c->nslots, c->kp_key, c->kp_level,
+                                       c->kp_count, c->kp_rot, c->desc, c->max_kp));
+    }
     return SLAMFE_OK;
 }
 
@@ -443,6 +479,7 @@ void slamfe_destroy(slamfe_ctx* c)
                     c->vis_uv.p, c->vis_idx.p, c->tri_in.p, c->tri_out.p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (hipEvent_t e : c->probe_ev) (void)hipEventDestroy(e);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -780,6 +817,7 @@ int slamfe_match_resident_batch(slamfe_ctx* c, uint64_t first_query, uint64_t fi
     slamfe_match_plan(c->max_kp, c->max_kp, npairs, c->p.match_kernel, &qpt, &chunk, &nchunks);
     int rc = grow(c, c->match_part, (size_t)npairs * nchunks * c->max_kp * 8);
     if (rc) return rc;
+    ProbeScope ps(c, SLAMFE_STAGE_MATCH);
     KCHK(c, slamfe_launch_match(c->stream, c->desc, 0, c->kp_count, c->desc, 0, c->kp_count, c->max_kp,
                                 qpt, chunk, nchunks, (uint32_t*)c->match_part.p,
                                 c->p.ratio, d_out, nullptr, 0, npairs,
@@ -1102,6 +1140,38 @@ int slamfe_search_by_projection_visible(slamfe_ctx* c, uint64_t frame, const int
     return search_projected(c, frame, kp_idx, n_inl, nullptr, nullptr, (const float*)c->vis_uv.p,
                             (const int32_t*)c->vis_idx.p, c->vis_count, radius, max_hamming,
                             matched_point_id);
+}
+
+int slamfe_debug_probe(slamfe_ctx* c, int stage)
+{
+    if (!c || stage < 0 || stage > SLAMFE_STAGE_MATCH) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    while (stage && c->probe_ev.size() < 128) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->probe_ev.push_back(e);
+    }
+    c->probe_stage = stage;
+    c->probe_used = 0;
+    return SLAMFE_OK;
+}
+
+int slamfe_debug_probe_read(slamfe_ctx* c, float* avg_ms, int* n)
+{
+    if (!c || !avg_ms) return SLAMFE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double sum = 0;
+    const int cnt = (int)(c->probe_used / 2);
+    for (int i = 0; i < cnt; ++i) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->probe_ev[2 * (size_t)i], c->probe_ev[2 * (size_t)i + 1]));
+        sum += ms;
+    }
+    *avg_ms = cnt ? (float)(sum / cnt) : 0.f;
+    if (n) *n = cnt;
+    return SLAMFE_OK;
 }
 
 int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, float* avg_ms)

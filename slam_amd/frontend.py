@@ -216,6 +216,17 @@ class FrontEnd:
                                                       C.byref(ms)))
         return ms.value
 
+    def probe_stage(self, stage: int):
+        """Measurement hook: record HIP events around `stage` of the calls that
+        follow (0 switches it off)."""
+        self._check(self._lib.slamfe_debug_probe(self._ctx, stage))
+
+    def probe_read(self):
+        """(mean milliseconds, number of intervals) recorded since probe_stage."""
+        ms, n = C.c_float(), C.c_int()
+        self._check(self._lib.slamfe_debug_probe_read(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def match_shard_keys(self, d_query: int, nq: int, d_train: int, nt: int, train_base: int,
                          d_keys: int):
         self._check(self._lib.slamfe_match_shard_keys(self._ctx, C.c_void_p(d_query), nq,
