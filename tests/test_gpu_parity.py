@@ -682,3 +682,27 @@ def test_reloc_2000_by_1M_properties():
         assert m["d0"][i] <= m["d1"][i] and m["nfound"][i] == 2
         # random 256-bit rows: the best of a million lies far below the mean of 128
         assert 60 < m["d0"][i] < 100
+
+
+def test_stage_probe_counts_intervals():
+    # the measurement hook: one interval per extraction while the probe is set,
+    # none after it is switched off, and the frame results are not affected
+    import torch
+    from slam_amd.frontend import FrontEnd
+    frames = synth.frame_stream(320, 240, 3, seed=5)
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=300, max_width=320, max_height=240,
+                  max_batch=3, frame_slots=12, map_capacity=0) as fe:
+        h0 = fe.extract_resident(d.data_ptr(), 3, 320, 240, 320, 320 * 240, 1)
+        ref = fe.frame_download(int(h0[1]))
+        fe.probe_stage(2)
+        for _ in range(3):
+            h = fe.extract_resident(d.data_ptr(), 3, 320, 240, 320, 320 * 240, 1)
+        ms, n = fe.probe_read()
+        assert n == 3 and 0.0 < ms < 50.0
+        got = fe.frame_download(int(h[1]))
+        assert np.array_equal(got.keypoints, ref.keypoints) and np.array_equal(got.descriptors, ref.descriptors)
+        fe.probe_stage(0)
+        fe.extract_resident(d.data_ptr(), 3, 320, 240, 320, 320 * 240, 1)
+        assert fe.probe_read()[1] == 0
