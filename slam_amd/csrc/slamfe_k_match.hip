@@ -597,6 +597,10 @@ int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int
     dim3 grid((unsigned)qblocks * (unsigned)nchunks * (unsigned)npairs);
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(d_query);
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(d_train);
+    // the matrix-core kernel keeps tile-relative row numbers in the low MM_SHIFT
+    // bits of its keys: a chunk may not span more tiles than MM_BIAS allows
+    if (qpt == 64 && ((chunk_rows + MM_TILE - 1) / MM_TILE - 1) * MM_TILE > (int)MM_BIAS)
+        return (int)hipErrorInvalidValue;
     if (qpt == 64)
         hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
     else if (qpt == 1)
