@@ -428,14 +428,10 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             // the high bytes of the four 16-bit results, in pixel order
             return __builtin_amdgcn_perm(neg[1], neg[0], 0x07030501u);
         };
-        // 63 lanes of a wave = 7 score rows x 9 tasks; wave w takes rows 7w .. 7w+6,
-        // then 28 rows further on: the lane's task column, LDS address and list
-        // value are set up once and advance by constants
-        const int lane = tid & 63, r7 = lane / (FB_COLD / 2), m = lane - r7 * (FB_COLD / 2);
-        const int sy_first = (tid >> 6) * 7 + r7;
-        const uint32_t* row = &tile32[(sy_first + 3) * FL_WD + FL_X0 / 4 + 2 * m];
-        for (int sy = sy_first; any_fast && sy - r7 < nrows + 2; sy += 28, row += 28 * FL_WD) {
-            if (lane == 63 || sy >= nrows + 2) continue;
+        for (int i = tid; any_fast && i < (nrows + 2) * (FB_COLD / 2); i += 256) {
+            int sy = i / (FB_COLD / 2), m = i - sy * (FB_COLD / 2);
+            int ly = sy + 3;
+            const uint32_t* row = &tile32[ly * FL_WD + FL_X0 / 4 + 2 * m];
             uint32_t C0 = row[0], C1 = row[1], Cp = row[-1], Cn = row[2];
             uint32_t U0 = row[-3 * FL_WD], U1 = row[-3 * FL_WD + 1];
             uint32_t D0 = row[3 * FL_WD], D1 = row[3 * FL_WD + 1];
