@@ -706,3 +706,18 @@ def test_stage_probe_counts_intervals():
         fe.probe_stage(0)
         fe.extract_resident(d.data_ptr(), 3, 320, 240, 320, 320 * 240, 1)
         assert fe.probe_read()[1] == 0
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (9, 33), (40, 40), (63, 70), (64, 64), (65, 65), (66, 200), (200, 66)])
+def test_extract_tiny_frames(w, h):
+    # frames smaller than a tile, than the border band, than the blur's reach:
+    # upper pyramid levels shrink to a few pixels; mostly nothing can be detected
+    from slam_amd.frontend import FrontEnd
+    img = synth.textured_canvas(w, h, 5 + w)
+    for mode in (abi.MODE_ORB, abi.MODE_PROVIDED):
+        for edge in (22, 31):
+            with FrontEnd(mode=mode, fast_threshold=10, nfeatures=500, max_width=w, max_height=h,
+                          edge_threshold=edge) as fe:
+                f = fe.extract_keypoints(img)
+                kps, desc = O.extract(oracle_params(fe), img)
+                assert_frame_equal(f, kps, desc)
