@@ -721,3 +721,16 @@ def test_extract_tiny_frames(w, h):
                 f = fe.extract_keypoints(img)
                 kps, desc = O.extract(oracle_params(fe), img)
                 assert_frame_equal(f, kps, desc)
+
+
+@pytest.mark.parametrize("w,h,nf", [(4096, 4096, 20000), (4096, 70, 3000), (70, 4096, 3000)])
+def test_extract_maximum_dimensions(w, h, nf):
+    # the largest frame the library accepts (SLAMFE_MAX_DIM = 4096) and the two
+    # most lopsided ones
+    from slam_amd.frontend import FrontEnd
+    img = synth.textured_canvas(w, h, 11)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=nf, max_width=w, max_height=h) as fe:
+        f = fe.extract_keypoints(img)
+        kps, desc = O.extract(oracle_params(fe), img)
+        assert len(kps) > 200
+        assert_frame_equal(f, kps, desc)
