@@ -734,3 +734,38 @@ def test_extract_maximum_dimensions(w, h, nf):
         kps, desc = O.extract(oracle_params(fe), img)
         assert len(kps) > 200
         assert_frame_equal(f, kps, desc)
+
+
+def test_match_maximum_train_rows():
+    # the largest shard one call accepts (2^23 - 1 rows): rows planted at chunk and
+    # tile boundaries and at both ends come back with their distance, both kernels
+    # agree, one row more is refused
+    import torch
+    from slam_amd.frontend import FrontEnd, SlamfeError
+    NT, NQ = (1 << 23) - 1, 300
+    train = synth.random_descriptors(NT, 5, 1)
+    query = synth.random_descriptors(NQ, 5, 2)
+    rows = np.array([0, 1, 31, 32, 2047, 2048, 2049, 4095, NT - 2049, NT - 2048, NT - 33, NT - 32,
+                     NT - 2, NT - 1])
+    for i, r in enumerate(rows):
+        query[i] = train[r]
+        query[i, 0] ^= (1 << (i % 8))  # one flipped bit
+    dq = torch.from_numpy(query).cuda()
+    dt = torch.from_numpy(train).cuda()
+    res = {}
+    for kern in (abi.MATCH_MATRIX, abi.MATCH_POPCOUNT):
+        keys = torch.empty((NQ, 2), dtype=torch.int64, device="cuda")
+        out = torch.zeros(NQ * 16, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        with FrontEnd(mode=abi.MODE_ORB, max_width=64, max_height=64, max_batch=1, map_capacity=0,
+                      match_kernel=kern) as fe:
+            fe.match_shard_keys(dq.data_ptr(), NQ, dt.data_ptr(), NT, 0, keys.data_ptr())
+            fe.merge_shard_keys(keys.data_ptr(), 1, NQ, out.data_ptr())
+            fe.sync()
+            res[kern] = out.cpu().numpy().view(abi.MATCH2_DTYPE).copy()
+            with pytest.raises(SlamfeError):
+                fe.match_shard_keys(dq.data_ptr(), NQ, dt.data_ptr(), NT + 1, 0, keys.data_ptr())
+    m, v = res[abi.MATCH_MATRIX], res[abi.MATCH_POPCOUNT]
+    for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+        assert np.array_equal(m[name], v[name]), name
+    assert np.array_equal(m["idx0"][:len(rows)], rows) and np.all(m["d0"][:len(rows)] == 1)
