@@ -769,3 +769,24 @@ def test_match_maximum_train_rows():
     for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
         assert np.array_equal(m[name], v[name]), name
     assert np.array_equal(m["idx0"][:len(rows)], rows) and np.all(m["d0"][:len(rows)] == 1)
+
+
+def test_search_by_projection_maximum_visible_points():
+    # 2^19 visible points (the most one call accepts): same answer as the CPU
+    # checker for 200 inliers; one point more is refused
+    from slam_amd.frontend import FrontEnd, SlamfeError
+    R = 1 << 19
+    img = synth.textured_canvas(1241, 376, 50)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=3000, max_width=1241, max_height=376,
+                  map_capacity=R + 8) as fe:
+        f = fe.extract_keypoints(img)
+        uv, pdesc = synth.local_map(f.descriptors, f.pt, R, 1241, 376, seed=7)
+        ids = np.arange(R, dtype=np.int32)
+        fe.map_put(ids, pdesc)
+        inl = synth.rand_below(8, 2, np.arange(200), len(f)).astype(np.int32)
+        got = fe.search_by_projection(f, inl, uv, ids)
+        want = O.search_by_projection(f.pt, f.descriptors, inl, uv, pdesc, ids)
+        assert np.array_equal(got, want) and (got >= 0).sum() > 150
+        with pytest.raises(SlamfeError) as e:
+            fe.search_by_projection(f, inl, np.concatenate([uv, uv[:1]]), np.arange(R + 1, dtype=np.int32))
+        assert e.value.code == abi.SLAMFE_E_CAPACITY
