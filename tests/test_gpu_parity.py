@@ -790,3 +790,24 @@ def test_search_by_projection_maximum_visible_points():
         with pytest.raises(SlamfeError) as e:
             fe.search_by_projection(f, inl, np.concatenate([uv, uv[:1]]), np.arange(R + 1, dtype=np.int32))
         assert e.value.code == abi.SLAMFE_E_CAPACITY
+
+
+def test_reproject_and_triangulate_a_million_points():
+    # sizes far beyond the reference's maps: 2^20 map points through the
+    # reprojection (ordered compaction over 4096 workgroups), 10^6 pairs through
+    # the triangulation; bit-exact against the CPU checker
+    from slam_amd.frontend import FrontEnd
+    n = 1 << 20
+    with FrontEnd(mode=abi.MODE_ORB, max_width=64, max_height=64, max_batch=1, map_capacity=n) as fe:
+        pose, K, xyz, th = synth.camera_scene(n, 1241, 376, 21)
+        fe.map_put_xyz(np.arange(n), xyz)
+        uv, idx = fe.reproject(pose, K, th, 1241, 376, n)
+        want_uv, want_idx = O.reproject(pose, K, xyz, th, 1241, 376)
+        assert len(want_idx) > n // 20
+        assert np.array_equal(idx, want_idx)
+        assert np.array_equal(uv.view(np.uint32), want_uv.view(np.uint32))
+        m = 1_000_000
+        P1, P2, p1, p2 = synth.two_view_scene(m, 640, 480, 33)
+        got = fe.triangulate(P1, P2, p1, p2)
+        want = O.triangulate(P1, P2, p1, p2)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
