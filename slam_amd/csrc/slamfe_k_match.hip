@@ -183,10 +183,12 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 // re-basing 16 constants) and made absolute at the end.
 //
 // Measured on MI355X (tools/ubench_mfma.hip, tools/time_match.py): the bare MFMA
-// chain with these operands runs at 4.9 POP/s (32.8 cycles per MFMA); the kernel
-// with chains only takes 0.28 ms for 2000 x 1M, fragment reads add 0.03, the top-2
-// update 0.04, expansion + barrier 0.10 -- they add up rather than overlap, and the
-// matrix pipes are busy 59 % of the kernel's cycles (SQ_VALU_MFMA_BUSY_CYCLES).
+// chain with these operands runs at 4.9 POP/s (32.8 cycles per MFMA), and two
+// chains with 8 independent vector operations per MFMA still at 39 cycles, so
+// issue port and matrix pipe do overlap; the kernel (about 6 vector operations
+// per MFMA after the key and lookup-table changes) takes 0.43 ms for 2000 x 1M
+// where the chains alone take 0.28: what remains is the hand-over between
+// stages (fragment reads after the barrier, expansion stores before it).
 // ---------------------------------------------------------------------------
 #define MM_TILE 32
 #define MM_SUB 2 /* tiles per LDS stage (one workgroup barrier per stage) */
