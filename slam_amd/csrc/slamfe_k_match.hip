@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 // 64 VGPRs per lane) x one chunk of train rows.  Train rows are read packed
 // (32 bytes), expanded to 0/64 bytes into LDS (one dword -> 32 bytes per thread
 // and tile, rows padded to 272 bytes so that the 16-byte fragment reads are
-// conflict-free), double-buffered in stages of two tiles.  A stage is one block
+// conflict-free), in three buffers of one stage (two tiles) each.  A stage is one block
 // of straight-line code: the 16 fragment reads of both tiles are issued first,
 // then the chains of tile t run while the vector ALU updates the top-2 from tile
 // t-1 (two accumulator sets) and expands the next stage's rows; 2 waves per SIMD
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                     uint32_t* __restrict__ part, slamfe_pair_slots ps,
                                                     slamfe_match_geo mg)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sA[2][MM_SUB][MM_TILE * MM_ROW];
+    __shared__ __attribute__((aligned(16))) uint8_t sA[3][MM_SUB][MM_TILE * MM_ROW];
     const int pair = (int)(blockIdx.x % (unsigned)mg.npairs);
     const int local = (int)(blockIdx.x / (unsigned)mg.npairs);
     if (ps.nslots) {
@@ -307,8 +307,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ntiles = (j1 - j0 + MM_TILE - 1) / MM_TILE;
     const int nstages = (ntiles + MM_SUB - 1) / MM_SUB;
     __syncthreads(); // the lookup table is complete
+    // Three stage buffers: the rows of stage s+1 are fetched from memory during
+    // stage s-1 and written to LDS in the middle of stage s, so that a wave reaches
+    // the barrier at the end of a stage with nothing of its own pending.
+    uint32_t nbits[MM_SUB];
 #pragma unroll
     for (int u = 0; u < MM_SUB; ++u) store_tile(0, u, load_bits(0, u));
+#pragma unroll
+    for (int u = 0; u < MM_SUB; ++u) nbits[u] = load_bits(1, u);
     __syncthreads();
 
     // result register j of lane half h is train row (j & 3) + 8 (j >> 2) + 4 h of the tile
@@ -377,28 +383,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // before them and the expansion of the next stage's rows share one block that
     // the compiler interleaves.  The last stage handles a short or missing tile.
     mm_v4i F[8], G[8];
+    int cur = 0; // buffer of the stage being computed
     for (int st = 0; st + 1 < nstages; ++st) {
-        uint32_t nbits[MM_SUB];
-#pragma unroll
-        for (int u = 0; u < MM_SUB; ++u) nbits[u] = load_bits(st + 1, u);
-        fetch(st & 1, 0, F);
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        fetch(cur, 0, F);
         // the second tile's fragments are on their way while the first tile's chains run
-        fetch(st & 1, 1, G);
+        fetch(cur, 1, G);
         __builtin_amdgcn_sched_barrier(0); // keep the compiler from sinking the reads to their uses
         compute(F, P0, P1);
+        // the next stage's rows (in registers since the previous stage) go to their
+        // buffer, which was last read two stages ago; then the loads for the stage
+        // after it start
+#pragma unroll
+        for (int u = 0; u < MM_SUB; ++u) store_tile(nxt, u, nbits[u]);
+#pragma unroll
+        for (int u = 0; u < MM_SUB; ++u) nbits[u] = load_bits(st + 2, u);
         // (in the first stage Q holds "no key" in every register and the update
         // changes nothing)
         extract(Q0, Q1, MM_TILE);
         compute(G, Q0, Q1);
         extract(P0, P1, MM_TILE);
-#pragma unroll
-        for (int u = 0; u < MM_SUB; ++u) store_tile((st + 1) & 1, u, nbits[u]);
         __syncthreads();
+        cur = nxt;
     }
     {
         const int st = nstages - 1;
-        fetch(st & 1, 0, F);
-        fetch(st & 1, 1, G);
+        fetch(cur, 0, F);
+        fetch(cur, 1, G);
         __builtin_amdgcn_sched_barrier(0);
         compute(F, P0, P1);
         extract(Q0, Q1, MM_TILE);
