@@ -401,6 +401,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (in the first stage Q holds "no key" in every register and the update
         // changes nothing)
         extract(Q0, Q1, MM_TILE);
+        // everything above is issued before the second tile's chains: the stores
+        // are out in mid-stage, not in front of the barrier
+        __builtin_amdgcn_sched_barrier(0);
         compute(G, Q0, Q1);
         extract(P0, P1, MM_TILE);
         __syncthreads();
