@@ -574,11 +574,13 @@ int slamfe_match_plan(int nq_max, int nt_max, int npairs, int kernel, int* qpt, 
     int rows, q;
     if (kernel == SLAMFE_MATCH_MATRIX || (kernel == SLAMFE_MATCH_AUTO && nq_max >= 128)) {
         // matrix-core kernel: a workgroup expands its 256 queries once (about the
-        // cost of three tiles), so chunks are long: 2048 rows for large train sets,
-        // 1024 for frame pairs (measured best on MI355X), less only when that
-        // would leave fewer than ~512 workgroups (a single frame pair)
+        // cost of three tiles) and its stages hand over through a barrier, so chunks
+        // are as long as the key format allows, 2048 rows (measured on MI355X: 256
+        // frame pairs 0.179 ms against 0.197 with 1024-row chunks and 0.230 with
+        // 512), less only when that would leave fewer than ~512 workgroups (a
+        // single frame pair)
         q = 64;
-        rows = nt_max > 8192 ? 2048 : 1024;
+        rows = 2048;
         while (rows > 256 && have * ((nt_max + rows - 1) / rows) < 512) rows >>= 1;
     } else {
         // few queries: the VALU kernel, one query row per lane.  Measured on MI355X:
