@@ -161,18 +161,19 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 // so one v_mfma_i32_32x32x32_i8 chain over the 256 bit positions (8 MFMAs) gives
 // the exact distances of 32 train rows x 32 queries, minus a per-query constant
 // that does not change the order.  The operands are stored scaled, train bits as
-// {0, 64} and query bits as {+64, -64}, so the chain delivers the distance times
-// 4096 = shifted left by 12, and the chain's initial accumulator holds
-// (256 << 12) + bias + row-in-tile per result register: the MFMA result IS the
-// key (distance << 12 | row), no instruction builds it.  In the result tile the
+// {0, -128} and query bits b as {-64, +64} (the product of a set train bit with b'
+// is then 8192 b'), so the chain delivers the distance times 8192 = shifted left
+// by 13, and the chain's initial accumulator holds (256 << 13) + bias +
+// row-in-tile per result register: the MFMA result IS the key (distance << 13 |
+// row), no instruction builds it.  In the result tile the
 // query is the lane (column) and the 16 registers are train rows, so the running
 // top-2 of a query stays in its lane: v_min / v_med3 per key as in the VALU
 // kernel, 2 VALU operations per comparison instead of 19; the 8 MFMAs of a tile
 // take 256 cycles per SIMD.
 //
-// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to +-64 bytes in
+// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to -+64 bytes in
 // 64 VGPRs per lane) x one chunk of train rows.  Train rows are read packed
-// (32 bytes), expanded to 0/64 bytes into LDS (one dword -> 32 bytes per thread
+// (32 bytes), expanded to 0 / 0x80 bytes into LDS (one dword -> 32 bytes per thread
 // and tile, rows padded to 272 bytes so that the 16-byte fragment reads are
 // conflict-free), in three buffers of one stage (two tiles) each.  A stage is one block
 // of straight-line code: the 16 fragment reads of both tiles are issued first,
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 #define MM_TILE 32
 #define MM_SUB 2 /* tiles per LDS stage (one workgroup barrier per stage) */
 #define MM_ROW 272
-#define MM_BIAS 2048u /* >= 32 * (tiles per chunk - 1), < 4096 - 31: chunks of at most 2080 rows */
-#define MM_SHIFT 12
+#define MM_BIAS 8128u /* >= 32 * (tiles per chunk - 1), < 8192 - 31: chunks of at most 8160 rows */
+#define MM_SHIFT 13
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
 
@@ -212,10 +213,10 @@ __device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x, int pos)
 {
     return (((x >> pos) & 0xFu) * 0x00204081u) & 0x01010101u;
 }
-// the same with 64 for a set bit
-__device__ __forceinline__ uint32_t bits4_to_bytes64(uint32_t x, int pos)
+// the same with 0x80 (-128 as int8) for a set bit
+__device__ __forceinline__ uint32_t bits4_to_bytes128(uint32_t x, int pos)
 {
-    return (((x >> pos) & 0xFu) * 0x08102040u) & 0x40404040u;
+    return (((x >> pos) & 0xFu) * 0x10204080u) & 0x80808080u;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_match_mfma(const uint32_t* __restrict__ query, int nq_imm,
@@ -258,11 +259,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
 
-    // byte -> eight 0/64 bytes: the expansion of the train rows is a table lookup
+    // byte -> eight 0 / 0x80 bytes: the expansion of the train rows is a table lookup
     // (4 LDS reads per dword instead of 24 vector operations; the kernel's time is
     // its vector issue slots as much as its matrix pipe)
     __shared__ uint2 lut[256];
-    lut[tid] = make_uint2(bits4_to_bytes64((uint32_t)tid, 0), bits4_to_bytes64((uint32_t)tid, 4));
+    lut[tid] = make_uint2(bits4_to_bytes128((uint32_t)tid, 0), bits4_to_bytes128((uint32_t)tid, 4));
 
     // query fragments: lane (r, h) holds bits 16h .. 16h+15 of every dword of its
     // query row as +-1 bytes
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const uint32_t t = bits4_to_bytes(half, 4 * n);
-                B[blk][kb][n] = (int)((((t << 8) - t) & 0x80808080u) | 0x40404040u); // bit 1 -> 0xc0 (-64), bit 0 -> 0x40 (+64)
+                B[blk][kb][n] = (int)((~((t << 8) - t) & 0x80808080u) | 0x40404040u); // bit 1 -> 0x40 (+64), bit 0 -> 0xc0 (-64)
             }
         }
         pq[blk] = pc;
@@ -575,13 +576,19 @@ int slamfe_match_plan(int nq_max, int nt_max, int npairs, int kernel, int* qpt, 
     if (kernel == SLAMFE_MATCH_MATRIX || (kernel == SLAMFE_MATCH_AUTO && nq_max >= 128)) {
         // matrix-core kernel: a workgroup expands its 256 queries once (about the
         // cost of three tiles) and its stages hand over through a barrier, so chunks
-        // are as long as the key format allows, 2048 rows (measured on MI355X: 256
-        // frame pairs 0.179 ms against 0.197 with 1024-row chunks and 0.230 with
-        // 512), less only when that would leave fewer than ~512 workgroups (a
-        // single frame pair)
+        // are long: up to what the key format allows (8128 rows) for large train
+        // sets, 4096 for frame pairs; shorter only when that would leave fewer than
+        // ~512 workgroups (a single frame pair).  Measured on MI355X: 2000 x 1M
+        // 4.79 / 4.86 / 5.01 T cmp/s with 2048 / 4096 / 8128 rows; 256 frame pairs
+        // 0.230 / 0.197 / 0.179 / 0.177 ms with 512 / 1024 / 2048 / 4096 rows.
         q = 64;
-        rows = 2048;
-        while (rows > 256 && have * ((nt_max + rows - 1) / rows) < 512) rows >>= 1;
+        static const int lengths[] = {8128, 4096, 2048, 1024, 512, 256};
+        rows = 256;
+        for (int r : lengths) {
+            if (r > 4096 && nt_max <= 8192) continue;
+            rows = r;
+            if (have * ((nt_max + r - 1) / r) >= 512) break;
+        }
     } else {
         // few queries: the VALU kernel, one query row per lane.  Measured on MI355X:
         // 256- or 512-row chunks beat 2 or 4 rows per lane by 7-13 %, and chunk
