@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             // the high bytes of the four 16-bit results, in pixel order
             return __builtin_amdgcn_perm(neg[1], neg[0], 0x07030501u);
         };
-        for (int i = tid; any_fast && i < (nrows + 2) * (FB_COLD / 2); i += 256) {
+        // (the tasks past the first 256 go to the last wave, those of the blur row
+        // pass below to the third: no wave gets both remainders)
+        for (int i = tid, it = 0; any_fast && it < 2; ++it, i = 256 + ((tid + 64) & 255)) {
+            if (i >= (nrows + 2) * (FB_COLD / 2)) continue;
             int sy = i / (FB_COLD / 2), m = i - sy * (FB_COLD / 2);
             int ly = sy + 3;
             const uint32_t* row = &tile32[ly * FL_WD + FL_X0 / 4 + 2 * m];
@@ -507,7 +510,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             uint32_t s3 = __builtin_amdgcn_udot4(d1, KA, 0, false);
             o[3] = __builtin_amdgcn_udot4(d2, KB, s3, false);
         };
-        for (int i = tid; i < ((nrows + 7) >> 1) * 16; i += 256) {
+        for (int i = tid, it = 0; it < 2; ++it, i = 256 + ((tid + 128) & 255)) {
+            if (i >= ((nrows + 7) >> 1) * 16) continue;
             int j = i >> 4, c = i & 15;
             const uint32_t* p = &tile32[(2 * j + 1) * FL_WD + FL_X0 / 4 + c]; // columns x0-4+4c .. +11
             uint32_t a[4], b[4];
