@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             // the high bytes of the four 16-bit results, in pixel order
             return __builtin_amdgcn_perm(neg[1], neg[0], 0x07030501u);
         };
-        // (the tasks past the first 256 go to the last wave, those of the blur row
-        // pass below to the third: no wave gets both remainders)
+        // (the tasks past the first 256 go to the last wave, which takes no part
+        // in the blur row pass below)
         for (int i = tid, it = 0; any_fast && it < 2; ++it, i = 256 + ((tid + 64) & 255)) {
             if (i >= (nrows + 2) * (FB_COLD / 2)) continue;
             int sy = i / (FB_COLD / 2), m = i - sy * (FB_COLD / 2);
@@ -510,8 +510,9 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             uint32_t s3 = __builtin_amdgcn_udot4(d1, KA, 0, false);
             o[3] = __builtin_amdgcn_udot4(d2, KB, s3, false);
         };
-        for (int i = tid, it = 0; it < 2; ++it, i = 256 + ((tid + 128) & 255)) {
-            if (i >= ((nrows + 7) >> 1) * 16) continue;
+        // (the last wave has the pretest's remainder: the row pass is shared by
+        // the other three)
+        for (int i = tid; tid < 192 && i < ((nrows + 7) >> 1) * 16; i += 192) {
             int j = i >> 4, c = i & 15;
             const uint32_t* p = &tile32[(2 * j + 1) * FL_WD + FL_X0 / 4 + c]; // columns x0-4+4c .. +11
             uint32_t a[4], b[4];
