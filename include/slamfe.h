@@ -199,6 +199,21 @@ int slamfe_match_resident_batch(slamfe_ctx* ctx, uint64_t first_query, uint64_t 
 int slamfe_match_shard_keys(slamfe_ctx* ctx, const void* d_query, int nq, const void* d_train,
                             int nt, int64_t train_base, uint64_t* d_keys);
 
+/* No counterpart in the reference.  slamfe_match_shard_keys for callers that
+ * cannot allocate device memory -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc: same arguments, same keys, but the
+ * per-chunk partial results live in a fixed 4 MiB device array of the library
+ * (one per GPU, held until the process ends) instead of a buffer that grows on
+ * demand, and the call makes no hipMalloc / hipFree.  The job must satisfy
+ * chunks(nt) * nq * 8 <= 4 MiB, where a chunk is 8128 train rows under the
+ * matrix-core kernel and 128 to 512 rows under the popcount kernel (2000 queries
+ * x 1,000,000 rows on the matrix cores need 1.9 MiB); beyond that it returns
+ * SLAMFE_E_CAPACITY and launches nothing.  All contexts on one GPU share the
+ * array: two such calls that overlap on one GPU (different streams) race.
+ * Asynchronous on the context's stream. */
+int slamfe_match_shard_keys_static(slamfe_ctx* ctx, const void* d_query, int nq, const void* d_train,
+                                   int nt, int64_t train_base, uint64_t* d_keys);
+
 /* Second half of the sharded form of Init.cc:131-153: merge nshards key sets (laid out [shard][nq][2], e.g. the output of an
  * all-gather) into match rows + ratio flag.  Asynchronous. */
 int slamfe_merge_shard_keys(slamfe_ctx* ctx, const uint64_t* d_keys_all, int nshards, int nq,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "slamfe_debug_probe": (C.c_int, [ctxp, C.c_int]),
     "slamfe_debug_probe_read": (C.c_int, [ctxp, f32p, C.POINTER(C.c_int)]),
     "slamfe_match_shard_keys": (C.c_int, [ctxp, vp, C.c_int, vp, C.c_int, C.c_int64, vp]),
+    "slamfe_match_shard_keys_static": (C.c_int, [ctxp, vp, C.c_int, vp, C.c_int, C.c_int64, vp]),
     "slamfe_merge_shard_keys": (C.c_int, [ctxp, vp, C.c_int, C.c_int, vp]),
     "slamfe_map_put": (C.c_int, [ctxp, vp, vp, C.c_int]),
     "slamfe_map_put_xyz": (C.c_int, [ctxp, vp, vp, C.c_int]),

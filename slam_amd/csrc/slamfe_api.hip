@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -38,6 +39,14 @@ struct Scratch {
 };
 
 } // namespace
+
+// Fixed device memory for slamfe_match_shard_keys_static: the per-chunk top-2
+// partials of one matching job.  Every GPU the library runs on holds its own
+// copy of this array at its own address until the process ends; the name below
+// is only the host-side handle of the symbol, never a device address: host code
+// uses the per-device pointer that static_scratch_for() looks up.
+#define SLAMFE_STATIC_SCRATCH_BYTES ((size_t)4 << 20)
+static __device__ __align__(256) unsigned char scratch[SLAMFE_STATIC_SCRATCH_BYTES];
 
 struct slamfe_ctx {
     slamfe_params p;
@@ -89,6 +98,7 @@ struct slamfe_ctx {
     Scratch rp_uv_all, rp_mask, rp_off, rp_total, vis_uv, vis_idx;
     Scratch tri_in, tri_out;
     int vis_count = -1;
+    void* static_scratch = nullptr; // this GPU's copy of `scratch` (device address)
     // in-pipeline stage probe (slamfe_debug_probe): events around one stage of
     // every extraction / batched match that is queued while the probe is set
     int probe_stage = 0;
@@ -155,6 +165,27 @@ int grow(slamfe_ctx* c, Scratch& s, size_t bytes)
     size_t want = bytes + bytes / 2 + 256;
     HIPCHK(c, hipMalloc(&s.p, want));
     s.bytes = want;
+    return SLAMFE_OK;
+}
+
+// Device address of `scratch` on `device` (which must be the current device):
+// looked up once per device, kept for the life of the process.
+#define SLAMFE_MAX_DEVICES 64
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[SLAMFE_MAX_DEVICES];
+
+int static_scratch_for(slamfe_ctx* c, int device, void** out)
+{
+    if (device < 0 || device >= SLAMFE_MAX_DEVICES)
+        return fail(c, SLAMFE_E_INVALID, "device ordinal %d; at most %d devices", device, SLAMFE_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIPCHK(c, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(c, SLAMFE_E_DEVICE, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
     return SLAMFE_OK;
 }
 
@@ -532,6 +563,10 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    {
+        int rc = static_scratch_for(c, p.device_id, &c->static_scratch);
+        if (rc) return rc;
+    }
     slamfe_dev_geom gmax;
     std::vector<uint32_t> tmax;
     build_geometry(p, p.max_width, p.max_height, &gmax, &tmax);
@@ -870,6 +905,34 @@ int slamfe_match_shard_keys(slamfe_ctx* c, const void* d_query, int nq, const vo
     KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)d_query, nq, nullptr,
                                 (const uint8_t*)d_train, nt, nullptr, nq, qpt, chunk, nchunks,
                                 (uint32_t*)c->match_part.p, c->p.ratio, nullptr, d_keys, train_base, 1,
+                                0, 0, 0));
+    return SLAMFE_OK;
+}
+
+int slamfe_match_shard_keys_static(slamfe_ctx* c, const void* d_query, int nq, const void* d_train, int nt,
+                                   int64_t train_base, uint64_t* d_keys)
+{
+    if (!c || nq < 0 || nt < 0 || !d_keys || (nq > 0 && !d_query) || (nt > 0 && !d_train))
+        return SLAMFE_E_INVALID;
+    if (nt >= SLAMFE_MAX_TRAIN)
+        return fail(c, SLAMFE_E_INVALID, "shard of %d rows; at most %d per call", nt,
+                    SLAMFE_MAX_TRAIN - 1);
+    if (nq == 0) return SLAMFE_OK;
+    if (!c->static_scratch) return fail(c, SLAMFE_E_DEVICE, "the context has no static scratch address");
+    HIPCHK(c, hipSetDevice(c->p.device_id));
+    int qpt, chunk, nchunks;
+    slamfe_match_plan(nq, nt, 1, c->p.match_kernel, &qpt, &chunk, &nchunks);
+    const size_t need = (size_t)nchunks * (size_t)nq * 8;
+    if (need > SLAMFE_STATIC_SCRATCH_BYTES)
+        return fail(c, SLAMFE_E_CAPACITY,
+                    "%d queries x %d train rows need %zu bytes of partial results; the static scratch "
+                    "holds %zu (use slamfe_match_shard_keys, or fewer queries / rows per call)",
+                    nq, nt, need, (size_t)SLAMFE_STATIC_SCRATCH_BYTES);
+    // every partial the merge reads is written by the match kernel of this call:
+    // nothing in the array has to start at zero
+    KCHK(c, slamfe_launch_match(c->stream, (const uint8_t*)d_query, nq, nullptr,
+                                (const uint8_t*)d_train, nt, nullptr, nq, qpt, chunk, nchunks,
+                                (uint32_t*)c->static_scratch, c->p.ratio, nullptr, d_keys, train_base, 1,
                                 0, 0, 0));
     return SLAMFE_OK;
 }

@@ -233,6 +233,13 @@ class FrontEnd:
                                                       C.c_void_p(d_train), nt,
                                                       C.c_int64(train_base), C.c_void_p(d_keys)))
 
+    def match_shard_keys_static(self, d_query: int, nq: int, d_train: int, nt: int, train_base: int,
+                                d_keys: int):
+        """``match_shard_keys`` without any device allocation (fixed scratch array)."""
+        self._check(self._lib.slamfe_match_shard_keys_static(self._ctx, C.c_void_p(d_query), nq,
+                                                             C.c_void_p(d_train), nt,
+                                                             C.c_int64(train_base), C.c_void_p(d_keys)))
+
     def merge_shard_keys(self, d_keys_all: int, nshards: int, nq: int, d_out: int):
         self._check(self._lib.slamfe_merge_shard_keys(self._ctx, C.c_void_p(d_keys_all), nshards, nq,
                                                       C.c_void_p(d_out)))
