@@ -13,15 +13,23 @@ steps.  With --gpus N every rank runs the same per-GPU workload on its own
 frames (frame batches shard with no collective): weak scaling, value = total
 frames/s.
 
-Also reported in the same JSON line:
-  roofline      the dominant kernel against the HBM roofline (algorithmic bytes
-                per launch / HIP-event time on the launch stream)
-  cpu_baseline  the scalar CPU port of the same path, timed on this host
-  hamming       G Hamming comparisons/s of the match kernel; with N > 1 also
-                the sharded relocalisation case (2000 queries x 1M map rows,
-                map split over the ranks, RCCL all-gather of per-shard top-2)
+Also reported in the same JSON line (never part of `value`):
+  roofline        the dominant kernel against the HBM roofline (algorithmic bytes
+                  per launch / HIP-event time on the launch stream) and the
+                  instruction-issue bound that actually limits it
+  parity_checked_frames   frames of the last timed step whose keypoints,
+                  descriptors and match rows were compared with the CPU checker
+  host_path       what the reference's host code can call (Init.cc:124-131):
+                  host frames in, results back -- batch rate and single-call times
+  configs         one leg per other BASELINE config (KITTI stream + search by
+                  projection, 256 x 1080p split over the ranks, 3840x2160)
+  cpu_baseline    the scalar CPU port of the same path, timed on this host
+  hamming         G Hamming comparisons/s of the match kernel; with N > 1 also
+                  the sharded relocalisation case (2000 queries x 1M map rows,
+                  map split over the ranks, RCCL all-gather of per-shard top-2)
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -34,15 +42,17 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from slam_amd import abi, synth  # noqa: E402
+from slam_amd import abi, sharding, synth  # noqa: E402
 from slam_amd.frontend import FrontEnd  # noqa: E402
 
 W, H, NFEAT, THR = 640, 480, 2000, 20
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TOPS = 41.0  # measured: tools/ubench_valu.hip, v_xor + accumulating v_bcnt
+VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, one per 4 cycles, 2.4 GHz
 MFMA_I8_PEAK_TOPS = 2048 * 1024 * 2.4e9 / 1e12  # dense int8 MFMA peak, 5033 TOP/s
 
 STAGES = {"pyramid": 1, "fast_blur": 2, "select": 3, "orient": 4, "describe": 6, "match": 7}
+MATCH_FIELDS = ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound")
 
 
 def level_sizes(w, h, nlevels=8, sf=1.2):
@@ -66,11 +76,25 @@ def algorithmic_bytes_per_frame(w, h):
     }
 
 
-def cpu_baseline(frames, budget_s=12.0):
-    """The scalar CPU port (test infrastructure in oracle/) on a bounded sample
-    of the same workload: extract + match against the previous frame."""
+def checker():
+    """The scalar CPU port under oracle/ (test infrastructure).  Used here only for
+    the cpu_baseline leg and to check outputs after the timed regions."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    return O
+
+
+def host_threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def cpu_baseline(frames, budget_s=12.0):
+    """The scalar CPU port on a bounded sample of the same workload: extract +
+    match against the previous frame, on one thread and on all host threads
+    (frames dealt to the threads; the port itself is single-threaded, as
+    OpenCV's FAST/ORB path is per image)."""
+    from concurrent.futures import ThreadPoolExecutor
+    O = checker()
     p = abi.reference_params(fast_threshold=THR, nfeatures=NFEAT)
     prev = None
     n = 0
@@ -78,10 +102,7 @@ def cpu_baseline(frames, budget_s=12.0):
     while True:
         img = frames[n % len(frames)]
         _, desc = O.extract(p, img)
-        if prev is not None:
-            O.match_knn2(prev, desc)
-        else:
-            O.match_knn2(desc, desc)
+        O.match_knn2(prev if prev is not None else desc, desc)
         prev = desc
         n += 1
         el = time.perf_counter() - t0
@@ -90,15 +111,29 @@ def cpu_baseline(frames, budget_s=12.0):
     out = {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"{n} frames of the same 640x480 stream, extract + 1 match each, "
                      f"{el:.1f} s, scalar C -O3, 1 thread"}
-    # matching alone: one thread, and query rows split over the host threads this
-    # process may use (OpenCV's batchDistance runs under parallel_for_)
-    from concurrent.futures import ThreadPoolExecutor
+    nthr = host_threads()
+
+    def chain(ix):  # one thread's share: consecutive frames, each matched with its predecessor
+        prev = None
+        for i in ix:
+            _, d = O.extract(p, frames[i % len(frames)])
+            O.match_knn2(prev if prev is not None else d, d)
+            prev = d
+        return len(ix)
+    per = max(2, int(out["value"] * 6.0))  # about 6 s of work per thread
+    with ThreadPoolExecutor(nthr) as ex:
+        t0 = time.perf_counter()
+        done = sum(ex.map(chain, [range(t * per, (t + 1) * per) for t in range(nthr)]))
+        par = time.perf_counter() - t0
+    out["all_threads"] = {"value": round(done / par, 2), "unit": "frames/s", "cores": nthr,
+                          "sample": f"{done} frames, {par:.1f} s, {nthr} threads"}
+    # matching alone: one thread, and query rows split over the host threads
+    # (OpenCV's batchDistance runs under parallel_for_)
     q = synth.random_descriptors(2000, 3, 5)
     t = synth.random_descriptors(100000, 4, 6)
     t0 = time.perf_counter()
     O.match_knn2(q, t)
     one = time.perf_counter() - t0
-    nthr = max(1, min(16, len(os.sched_getaffinity(0))))
     parts = [np.ascontiguousarray(q[ix]) for ix in np.array_split(np.arange(len(q)), nthr)]
     with ThreadPoolExecutor(nthr) as ex:
         t0 = time.perf_counter()
@@ -128,6 +163,272 @@ def hbm_copy_ceiling(dev, nbytes=1 << 30, reps=10):
     return 2 * nbytes / (ms * 1e-3) / 1e9
 
 
+def pmc_profile():
+    """Counter readings of the committed rocprofv3 --pmc passes (they cannot be
+    collected inside this process)."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(tpath))
+    except Exception:
+        return {}
+
+
+def hbm_roofline(kernel, alg_bytes, ms, extra=None):
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(ms, 5)}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def timed(fn, reps, sync, warm=2):
+    for _ in range(warm):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def call_times_ms(fn, reps, warm=5):
+    """(median, mean) milliseconds of one synchronous call: the median is the
+    call's latency, the mean also carries the occasional host hiccup."""
+    for _ in range(warm):
+        fn()
+    ts = np.empty(reps)
+    for i in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts[i] = time.perf_counter() - t0
+    return float(np.median(ts)) * 1e3, float(ts.mean()) * 1e3
+
+
+class HostCall:
+    """slamfe_extract / slamfe_extract_batch / slamfe_match_frames through the C ABI
+    with preallocated outputs: what a C++ host pays, without Python allocations."""
+
+    def __init__(self, fe, nframes=1):
+        self.fe = fe
+        cap = fe.max_keypoints
+        self.cap = cap
+        self.kps = np.zeros((nframes, cap), abi.KEYPOINT_DTYPE)
+        self.desc = np.zeros((nframes, cap, 32), np.uint8)
+        self.rows = np.zeros(cap, abi.MATCH2_DTYPE)
+        self.counts = np.zeros(nframes, np.int32)
+        self.handles = np.zeros(nframes, np.uint64)
+        self.n = C.c_int32()
+
+    def extract(self, img):
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else 3
+        rc = self.fe._lib.slamfe_extract(self.fe._ctx, img.ctypes.data, w, h, w * ch, ch, self.kps.ctypes.data,
+                                         self.desc.ctypes.data, self.cap,
+                                         self.counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         self.handles.ctypes.data_as(C.POINTER(C.c_uint64)))
+        assert rc == 0, rc
+        return int(self.handles[0])
+
+    def extract_batch(self, ptrs, n, w, h):
+        rc = self.fe._lib.slamfe_extract_batch(self.fe._ctx, ptrs, n, w, h, w, 1, self.kps.ctypes.data,
+                                               self.desc.ctypes.data, self.cap,
+                                               self.counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               self.handles.ctypes.data_as(C.POINTER(C.c_uint64)))
+        assert rc == 0, rc
+
+    def match_frames(self, hq, ht):
+        rc = self.fe._lib.slamfe_match_frames(self.fe._ctx, C.c_uint64(hq), C.c_uint64(ht),
+                                              self.rows.ctypes.data, self.cap, C.byref(self.n))
+        assert rc == 0, rc
+        return self.n.value
+
+
+def leg_host_path(local_rank):
+    """The path the reference's tracking thread can call today (Init.cc:124-131):
+    frames in pageable host memory, keypoints / descriptors / match rows back in
+    host memory, one context, one host thread."""
+    out = {}
+    B = 64
+    frames = list(synth.frame_stream(W, H, B, seed=1))
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=THR, nfeatures=NFEAT, max_width=W, max_height=H,
+                  max_batch=B, frame_slots=2 * B, device_id=local_rank, map_capacity=0) as fe:
+        hc = HostCall(fe, B)
+        ptrs = (C.c_void_p * B)(*[f.ctypes.data for f in frames])
+        t = timed(lambda: hc.extract_batch(ptrs, B, W, H), 10, fe.sync)
+        out["host_batch_fps"] = round(B / t, 1)
+        out["host_batch"] = {"frames_per_call": B, "ms_per_call": round(t * 1e3, 4),
+                             "what": "slamfe_extract_batch: 64 pageable 640x480 frames in, keypoints + "
+                                     "descriptors back to host memory (PCIe both ways)"}
+    single = {}
+    cases = (("vga_orb_2000_thr20", W, H, NFEAT, THR, abi.MODE_ORB),
+             ("kitti_1241x376_provided_thr30", 1241, 376, 10000, 30, abi.MODE_PROVIDED),
+             ("kitti_1241x376_orb_3000_thr20", 1241, 376, 3000, 20, abi.MODE_ORB))
+    for name, w, h, nf, thr, mode in cases:
+        a, b = synth.frame_stream(w, h, 2, seed=3)
+        with FrontEnd(mode=mode, fast_threshold=thr, nfeatures=nf, max_width=w, max_height=h,
+                      device_id=local_rank, map_capacity=0) as fe:
+            hc = HostCall(fe)
+            ext_med, ext_mean = call_times_ms(lambda: hc.extract(a), 100)
+            st = {"prev": hc.extract(a)}
+
+            def loop():  # Init.cc:130-131: extract the new frame, match the previous one against it
+                cur = hc.extract(b)
+                hc.match_frames(st["prev"], cur)
+                st["prev"] = cur
+            loop_med, loop_mean = call_times_ms(loop, 100)
+            single[name] = {"extract_ms": round(ext_med, 4), "extract_mean_ms": round(ext_mean, 4),
+                            "extract_plus_match_ms": round(loop_med, 4),
+                            "extract_plus_match_mean_ms": round(loop_mean, 4),
+                            "frames_per_s": round(1e3 / loop_mean, 1), "keypoints": int(hc.counts[0])}
+    out["single_call_ms"] = single
+    return out
+
+
+def leg_config2(local_rank, check):
+    """BASELINE config 2: KITTI-size 1241x376 stream, 3000 features per frame,
+    search by projection against 20 000 local map points; one frame at a time
+    through the host-pointer calls, as Init.cc:124-259 would drive it."""
+    w, h, nfeat, npts = 1241, 376, 3000, 20000
+    frames = synth.frame_stream(w, h, 2, seed=9)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=THR, nfeatures=nfeat, max_width=w, max_height=h,
+                  max_batch=2, device_id=local_rank, map_capacity=npts) as fe:
+        f0, f1 = fe.extract_batch(list(frames))
+        m = fe.knn_match_frames(f0, f1)
+        uv, pdesc = synth.local_map(f1.descriptors, f1.pt, npts, w, h, seed=11)
+        ids = np.arange(npts, dtype=np.int32)
+        fe.map_put(ids, pdesc)
+        inl = m["idx0"][m["ratio_pass"] == 1].astype(np.int32)
+        hc = HostCall(fe)
+        t_ext = timed(lambda: hc.extract(frames[1]), 30, fe.sync)
+        fe.probe_stage(STAGES["fast_blur"])
+        for _ in range(8):
+            hc.extract(frames[1])
+        fb_ms, _ = fe.probe_read()
+        fe.probe_stage(0)
+        f0, f1 = fe.extract_batch(list(frames))
+        t_match = timed(lambda: hc.match_frames(f0.handle, f1.handle), 30, fe.sync)
+        matched = np.zeros(len(inl), np.int32)
+
+        def search():
+            rc = fe._lib.slamfe_search_by_projection(fe._ctx, C.c_uint64(f1.handle), inl.ctypes.data, len(inl),
+                                                     uv.ctypes.data, ids.ctypes.data, npts, C.c_float(32.0), 128,
+                                                     matched.ctypes.data)
+            assert rc == 0, rc
+        t_proj = timed(search, 30, fe.sync)
+        got = matched.copy()
+    alg = algorithmic_bytes_per_frame(w, h)["fast_blur"]
+    area = np.pi * 32.0 ** 2 / (w * h)
+    out = {"workload": "1241x376 stream, 3000 features, search by projection vs 20k map points, one frame "
+                       "per call, host frames in / results out",
+           "keypoints": len(f1), "inliers": int(len(inl)), "matched_points": int((got >= 0).sum()),
+           "extract_call_ms": round(t_ext * 1e3, 4), "match_call_ms": round(t_match * 1e3, 4),
+           "search_by_projection_call_ms": round(t_proj * 1e3, 4),
+           "frames_per_s": round(1.0 / (t_ext + t_match + t_proj), 1),
+           "search": {"brute_force_pairs": int(len(inl)) * npts,
+                      "brute_force_pairs_per_s": round(len(inl) * npts / t_proj, 1),
+                      "grid_candidates_per_inlier_expected": round(area * npts, 1),
+                      "window_candidates_per_s": round(len(inl) * area * npts / t_proj, 1)},
+           "roofline": hbm_roofline("k_fast_blur (one 1241x376 frame per launch: latency-bound)", alg, fb_ms)}
+    if check:
+        O = checker()
+        t0 = time.perf_counter()
+        want = O.search_by_projection(f1.pt, f1.descriptors, inl, uv, pdesc, ids)
+        out["cpu_port_search_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        assert np.array_equal(got, want), "search by projection differs from the CPU checker"
+        out["identical_to_cpu_port"] = True
+    return out
+
+
+def leg_extract_config(name, w, h, nfeat, total_frames, distinct, dev, local_rank, world, rank, multi, check,
+                       include_h2d):
+    """A fixed batch of `total_frames` frames split over the ranks (strong scaling,
+    no collective on the data path): each rank uploads its share from pinned
+    host memory (when include_h2d) and extracts it; results stay on the device."""
+    lo, hi = sharding.frame_bounds(total_frames, world, rank)
+    mine = hi - lo
+    uniq = synth.frame_stream(w, h, min(distinct, total_frames), seed=100)
+    idx = [i % len(uniq) for i in range(lo, hi)]
+    host = np.ascontiguousarray(uniq[idx]) if mine else np.zeros((0, h, w), np.uint8)
+    res = {"workload": f"{total_frames} frames of {w}x{h}, {nfeat} features each, split over {world} rank(s) "
+                       f"({len(uniq)} distinct frames repeated)", "frames_this_rank": mine}
+    B = max(1, mine)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=THR, nfeatures=nfeat, max_width=w, max_height=h,
+                  max_batch=B, frame_slots=B + 2, device_id=local_rank, map_capacity=0) as fe:
+        d = torch.empty((B, h, w), dtype=torch.uint8, device=dev)
+        # the frames wait in pinned host memory, where a capture pipeline would put them
+        host_t = torch.from_numpy(host).pin_memory() if mine else None
+        state = {}
+
+        def run(h2d):
+            if mine == 0:
+                return
+            if h2d:
+                d[:mine].copy_(host_t, non_blocking=True)  # host memory -> HBM over PCIe
+                torch.cuda.synchronize(dev)  # torch's stream; the library runs on its own
+            state["hd"] = fe.extract_resident(d.data_ptr(), mine, w, h, w, w * h, 1)
+
+        def measure(h2d, reps):
+            run(h2d)
+            fe.sync()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run(h2d)
+            fe.sync()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            el = (time.perf_counter() - t0) / reps
+            if multi:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el
+        if mine:
+            d[:mine].copy_(host_t)
+        torch.cuda.synchronize(dev)
+        t_res = measure(False, 5)
+        res["resident_fps"] = round(total_frames / t_res, 1)
+        res["resident_ms_per_batch"] = round(t_res * 1e3, 3)
+        if include_h2d:
+            t_h2d = measure(True, 3)
+            res["with_h2d_fps"] = round(total_frames / t_h2d, 1)
+            res["with_h2d_ms_per_batch"] = round(t_h2d * 1e3, 3)
+        if mine:
+            fe.probe_stage(STAGES["fast_blur"])
+            for _ in range(4):
+                run(False)
+            fb_ms, _ = fe.probe_read()
+            fe.probe_stage(0)
+            res["roofline"] = hbm_roofline("k_fast_blur", algorithmic_bytes_per_frame(w, h)["fast_blur"] * mine, fb_ms,
+                                           {"frames_per_launch": mine})
+            stage = {}
+            for sname, sid in STAGES.items():
+                if sname != "match":
+                    stage[sname] = round(fe.time_stage(sid, mine, 3), 4)
+            res["stage_ms_back_to_back"] = stage
+        if check and mine:
+            O = checker()
+            p = abi.reference_params(fast_threshold=THR, nfeatures=nfeat)
+            checked = []
+            for k in sorted({0, min(7, mine - 1), min(8, mine - 1), mine - 1}):
+                f = fe.frame_download(int(state["hd"][k]))
+                t0 = time.perf_counter()
+                kps, desc = O.extract(p, host[k])
+                res["cpu_port_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3, 1)
+                assert np.array_equal(f.keypoints, kps) and np.array_equal(f.descriptors, desc), \
+                    f"{name}: frame {k} differs from the CPU checker"
+                checked.append(lo + k)
+            res["parity_checked_frames"] = checked
+    res["scaling"] = "strong"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,8 +439,10 @@ def main():
                     help="untimed load before the warm-up steps so that the GPU clock has settled")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent frame streams per GPU, each with its own context and HIP stream")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true",
+                    help="skip everything that runs the CPU checker (baseline leg and output checks)")
     ap.add_argument("--no-reloc", action="store_true", help="skip the 1M-row matching leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the host-path and other-config legs")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group, barriers, all-gather) even "
                          "with one rank: a rehearsal of the N > 1 run on a one-GPU box")
@@ -222,13 +525,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # keypoints per frame, for the record (and to derive comparison counts)
-    counts = np.array([len(fe.frame_download(int(h)).keypoints) for h in hd[:4]])
-    all_counts = []
-    for h in hd:
-        f = fe.frame_download(int(h))
-        all_counts.append(len(f))
-    all_counts = np.array(all_counts, dtype=np.int64)
+    # The outputs of the last timed step, kept for the check against the CPU
+    # checker further down: frames 0, 7, 8 and B-1 (both sides of the 8-frame
+    # grouping of the launch grids, and the last frame), each with the frame it
+    # was matched against and its match rows.
+    check_ix = sorted({0, min(7, B - 1), min(8, B - 1), B - 1})
+    need = sorted({i for k in check_ix for i in (k, (k - 1) % B)})
+    kept = {i: fe.frame_download(int(hd[i])) for i in need}
+    kept_rows = {k: match_outs[0][k].cpu().numpy().reshape(-1).view(abi.MATCH2_DTYPE) for k in check_ix}
+    all_counts = np.array([len(fe.frame_download(int(h))) for h in hd], dtype=np.int64)
 
     # per-stage kernel time inside the running pipeline: HIP events around the
     # stage on the stream the kernels are launched on, over extra (untimed) steps
@@ -251,26 +556,25 @@ def main():
     # the roofline object is given for the slowest HBM-streaming kernel
     # (the pyramid stage is seven launches; FAST + blur is one fused launch)
     roof_bytes = alg[hbm_stage] * B
-    achieved = roof_bytes / (stage_ms[hbm_stage] * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            # measured on launches of tj["frames_per_launch"] frames; traffic is
-            # per frame-proportional, scaled to this run's batch
-            traffic = tj.get(hbm_stage)
-            if traffic is not None:
-                traffic = int(traffic * B / tj.get("frames_per_launch", B))
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "k_" + hbm_stage if hbm_stage != "pyramid" else "k_resize (7 launches)",
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": roof_bytes,
-                "avg_launch_ms": round(stage_ms[hbm_stage], 5),
-                "avg_launch_ms_back_to_back": round(isolated_ms, 5),
-                "measured_copy_ceiling_GBps": round(hbm_copy_ceiling(dev), 1)}
+    prof = pmc_profile()
+    roofline = hbm_roofline("k_" + hbm_stage if hbm_stage != "pyramid" else "k_resize (7 launches)",
+                            roof_bytes, stage_ms[hbm_stage],
+                            {"avg_launch_ms_back_to_back": round(isolated_ms, 5),
+                             "measured_copy_ceiling_GBps": round(hbm_copy_ceiling(dev), 1)})
+    traffic = prof.get(hbm_stage)
+    if traffic is not None:
+        # measured on launches of prof["frames_per_launch"] frames; per frame-proportional
+        roofline["traffic"] = int(traffic * B / prof.get("frames_per_launch", B))
+    winsts = prof.get(hbm_stage + "_wave_insts")
+    if winsts is not None:
+        # What actually bounds the kernel: vector-instruction issue.  One wave
+        # instruction per 4 cycles per SIMD; the count comes from the committed
+        # SQ_INSTS_* counter pass, the time from this run.
+        winsts = winsts * B / prof.get("frames_per_launch", B)
+        issue_ms = winsts / VALU_ISSUE_PER_S * 1e3
+        roofline["limiter"] = {"bound": "vector instruction issue", "wave_insts_per_launch": int(winsts),
+                               "peak_wave_insts_per_s": VALU_ISSUE_PER_S, "issue_time_ms": round(issue_ms, 5),
+                               "frac": round(issue_ms / stage_ms[hbm_stage], 4)}
 
     # Hamming comparisons/s of the match kernel inside the frame pipeline
     # (a step matches B pairs in one call: frame i with frame i-1, frame 0 with
@@ -292,8 +596,7 @@ def main():
     if not args.no_reloc:
         try:
             NQ, NT = 2000, 1_000_000
-            per = (NT + world - 1) // world
-            lo, hi = rank * per, min(NT, (rank + 1) * per)
+            lo, hi = sharding.shard_bounds(NT, world, rank)
             q_np = synth.random_descriptors(NQ, 3, 5)
             shard = torch.from_numpy(synth.random_descriptors(hi - lo, 3 + 101 * rank, 6)).to(dev)
             dq = torch.from_numpy(q_np).to(dev)
@@ -383,6 +686,7 @@ def main():
             hamming["reloc_mfma_frac"] = round(NQ * NT * R / rel / 1e12 * 512 / (MFMA_I8_PEAK_TOPS * world), 4)
             hamming["reloc_ms_per_query_set"] = round(rel / R * 1e3, 4)
             hamming["reloc_scaling"] = "strong (map rows split over ranks, RCCL all-gather of top-2 keys)"
+            del shard
         except Exception as e:  # the headline number must survive a failure of this leg
             hamming["reloc_error"] = repr(e)
 
@@ -411,11 +715,54 @@ def main():
         "dominant_stage": dominant,
         "hamming": hamming,
     }
-    if rank == 0 and world == 1 and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline(frames_np)
-        result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
     for f in fes:
         f.close()
+    del frames, match_outs
+    check = not args.no_cpu
+
+    # The timed batch against the CPU checker (rank 0's frames): keypoints,
+    # descriptors and the match rows of the checked frames must be identical.
+    if check and rank == 0:
+        O = checker()
+        p = abi.reference_params(fast_threshold=THR, nfeatures=NFEAT)
+        want = {i: O.extract(p, frames_np[i]) for i in need}
+        for i in need:
+            assert np.array_equal(kept[i].keypoints, want[i][0]), f"bench frame {i}: keypoints differ from the CPU checker"
+            assert np.array_equal(kept[i].descriptors, want[i][1]), f"bench frame {i}: descriptors differ"
+        for k in check_ix:
+            ref = O.match_knn2(want[(k - 1) % B][1], want[k][1])  # query = previous frame, train = frame k
+            got = kept_rows[k][:len(ref)]
+            for name in MATCH_FIELDS:
+                assert np.array_equal(got[name], ref[name]), f"bench frame {k}: match rows differ ({name})"
+        result["parity_checked_frames"] = check_ix
+
+    # Legs outside the headline: the host-pointer path and the other BASELINE
+    # configs.  Each is fenced: the headline line survives a failure of any of them.
+    if not args.no_legs:
+        legs = {}
+        if world == 1 and not multi:
+            for name, fn in (("host_path", lambda: leg_host_path(local_rank)),
+                             ("config2_kitti_search_by_projection", lambda: leg_config2(local_rank, check)),
+                             ("config5_3840x2160_10k_features",
+                              lambda: leg_extract_config("config5", 3840, 2160, 10000, 4, 4, dev, local_rank, 1, 0,
+                                                         False, check, False))):
+                try:
+                    legs[name] = fn()
+                except Exception as e:
+                    legs[name] = {"error": repr(e)}
+        try:
+            # config 3: the fixed batch of 256 x 1080p frames split over the ranks
+            legs["config3_256x1080p_5k_features"] = leg_extract_config(
+                "config3", 1920, 1080, 5000, 256, 32, dev, local_rank, world, rank, multi, check and rank == 0, True)
+        except Exception as e:
+            legs["config3_256x1080p_5k_features"] = {"error": repr(e)}
+        if "host_path" in legs:
+            result["host_path"] = legs.pop("host_path")
+        result["configs"] = legs
+
+    if rank == 0 and world == 1 and check:
+        result["cpu_baseline"] = cpu_baseline(frames_np)
+        result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

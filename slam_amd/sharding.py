@@ -26,6 +26,19 @@ def shard_bounds(nrows: int, world: int, rank: int):
     return lo, hi
 
 
+def frame_bounds(nframes: int, world: int, rank: int):
+    """Contiguous slice [lo, hi) of a batch of `nframes` frames extracted by
+    `rank`: frames are independent (Init.cc:124-130 handles one per iteration), so a
+    batch splits over GPUs with no exchange; the first nframes % world ranks take
+    one frame more.  Concatenating the ranks' results in rank order gives the
+    single-device result."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank outside the world")
+    base, extra = divmod(max(nframes, 0), world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
 def match_rows_to_keys(rows: np.ndarray, train_base: int) -> np.ndarray:
     """[nq, 2] uint64 keys from match rows whose indices are shard-local."""
     nq = len(rows)

@@ -558,6 +558,41 @@ def test_config3_1920x1080_5000_features():
     _full_size_case(1920, 1080, 5000, 100)
 
 
+@pytest.mark.parametrize("nframes", [9])
+def test_config3_1080p_batch_through_the_resident_calls(nframes):
+    # BASELINE config 3 as the benchmark drives it: a batch of 1920x1080 frames, 5000
+    # features each, resident in device memory, through slamfe_extract_resident and
+    # slamfe_match_resident_batch.  Nine frames leave the second XCD group ragged
+    # (frame = blockIdx.z * 8 + blockIdx.x) and k_resize's four-frames-per-wave
+    # layout with an incomplete group.  Every frame and every pair is compared.
+    import torch
+    from slam_amd.frontend import FrontEnd
+    w, h, nfeat = 1920, 1080, 5000
+    frames = synth.frame_stream(w, h, nframes, seed=33)
+    d = torch.from_numpy(frames).cuda()
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=nfeat, max_width=w, max_height=h,
+                  max_batch=nframes, frame_slots=2 * nframes, map_capacity=0) as fe:
+        cap = fe.max_keypoints
+        out = torch.zeros((nframes - 1, cap, 16), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the fills run on torch's stream, the library on its own
+        hd = fe.extract_resident(d.data_ptr(), nframes, w, h, w, w * h, 1)
+        fe.match_resident_batch(int(hd[0]), int(hd[1]), nframes - 1, out.data_ptr())
+        fe.sync()
+        p = oracle_params(fe)
+        want = [O.extract(p, fr) for fr in frames]
+        quotas = O.level_quotas(nfeat)
+        for i in range(nframes):
+            kps, desc = want[i]
+            assert len(kps) >= nfeat and np.all(np.bincount(kps["octave"], minlength=8) >= quotas)
+            assert_frame_equal(fe.frame_download(int(hd[i])), kps, desc)
+        rows = out.cpu().numpy()
+        for i in range(nframes - 1):
+            m = np.frombuffer(rows[i].tobytes(), dtype=abi.MATCH2_DTYPE)[:len(want[i][0])]
+            ref = O.match_knn2(want[i][1], want[i + 1][1])
+            for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+                assert np.array_equal(m[name], ref[name]), (i, name)
+
+
 def test_config5_3840x2160_10000_features():
     # 60 tiles per band: the selection sort needs the >64 KiB dynamic-LDS path
     _full_size_case(3840, 2160, 10000, 5)

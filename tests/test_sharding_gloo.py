@@ -1,6 +1,9 @@
-"""The N > 1 path on CPU: two gloo ranks each match the queries against their
+"""The N > 1 paths on CPU.  Matching: two gloo ranks each match the queries against their
 shard (the CPU checker stands in for the per-shard kernel), all-gather the
-top-2 keys, merge, and must equal the single-process result."""
+top-2 keys, merge, and must equal the single-process result.  Extraction: the
+ranks take contiguous slices of one frame batch (no exchange on the data path;
+the gather below only brings the results to the test) and the concatenation
+must equal the single-process results."""
 import os
 import socket
 import sys
@@ -67,3 +70,60 @@ def test_shard_bounds_cover_everything_once():
             assert spans[0][0] == 0 and spans[-1][1] == n
             for (a, b), (c, d) in zip(spans, spans[1:]):
                 assert b == c and a <= b
+
+
+def _extract_worker(rank, world, port, nframes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slam_amd import abi
+    frames = synth.frame_stream(160, 120, nframes, seed=12)
+    p = abi.reference_params(fast_threshold=20, nfeatures=150)
+    lo, hi = sharding.frame_bounds(nframes, world, rank)
+    mine = [O.extract(p, frames[i]) for i in range(lo, hi)]  # the checker stands in for the GPU
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, mine))
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nframes", [5, 1])
+def test_two_rank_sharded_extraction_equals_single(nframes):
+    from slam_amd import abi
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_extract_worker, args=(r, 2, port, nframes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames = synth.frame_stream(160, 120, nframes, seed=12)
+    p = abi.reference_params(fast_threshold=20, nfeatures=150)
+    results = []
+    expect_lo = 0
+    for lo, hi, part in gathered:  # rank order = frame order
+        assert lo == expect_lo and len(part) == hi - lo
+        expect_lo = hi
+        results += part
+    assert expect_lo == nframes and len(results) == nframes
+    for i in range(nframes):
+        kps, desc = O.extract(p, frames[i])
+        assert np.array_equal(results[i][0], kps) and np.array_equal(results[i][1], desc)
+
+
+def test_frame_bounds_cover_the_batch_once_and_evenly():
+    for n in (0, 1, 7, 255, 256, 257):
+        for w in (1, 2, 3, 4, 8):
+            spans = [sharding.frame_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+    with pytest.raises(ValueError):
+        sharding.frame_bounds(4, 2, 2)
