@@ -8,7 +8,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslamfe.so")
+# SLAMFE_LIB names another build of the same library (A/B timing of kernels)
+LIB_PATH = os.environ.get("SLAMFE_LIB") or os.path.join(_HERE, "libslamfe.so")
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int32)

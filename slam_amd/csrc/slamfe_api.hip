@@ -84,13 +84,14 @@ struct slamfe_ctx {
     slamfe_keypoint* kps = nullptr;
     uint8_t* desc = nullptr;
     std::vector<uint64_t> slot_handle;
+    std::vector<int32_t> slot_count_host; // keypoint count of a slot once the host has read it, else -1
     uint64_t next_seq = 1; // handle = sequence number; slot = seq % nslots
 
     slamfe_match2* match_out = nullptr; // [max_kp]
     int fm_qpt = 1, fm_chunk = 64, fm_nchunks = 1; // plan for frame-vs-frame matching
     Scratch match_part, match_q, match_t, match_o;
     uint8_t* map_desc = nullptr;
-    Scratch pj_idx, pj_uv, pj_ids, pj_cand, pj_candn, pj_matched;
+    Scratch pj_in, pj_cand, pj_candn, pj_matched, pj_cells, pj_sorted;
     Scratch ing_taps, ing_bgr;
     // reprojection: coordinates table (row = Point::id), scratch, and the visible
     // set the last slamfe_reproject call left on the device
@@ -356,6 +357,7 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     for (int i = 0; i < n; ++i) {
         uint64_t hdl = seq0 + (uint64_t)i;
         c->slot_handle[(size_t)(hdl % (uint64_t)c->nslots)] = hdl;
+        c->slot_count_host[(size_t)(hdl % (uint64_t)c->nslots)] = -1;
         if (handles) handles[i] = hdl;
     }
     c->next_seq += (uint64_t)n;
@@ -420,6 +422,7 @@ int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kp
     std::vector<int> ncopy((size_t)nf, 0);
     for (int i = 0; i < nf; ++i) {
         int n = c->h_cnt[i];
+        c->slot_count_host[(size_t)slots[i]] = n;
         if (n_out) n_out[i] = n;
         if (n > c->max_kp) {
             worst = fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the context's max_keypoints %d", n,
@@ -504,8 +507,8 @@ void slamfe_destroy(slamfe_ctx* c)
     void* bufs[] = {c->pyr, c->blur, c->in_stage, c->taps, c->cand, c->cand_cnt, c->band_hist,
                     c->band_off, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
                     c->kp_count, c->kps, c->desc, c->kp_mom, c->kp_rot, c->match_out, c->map_desc, c->match_part.p,
-                    c->match_q.p, c->match_t.p, c->match_o.p, c->pj_idx.p, c->pj_uv.p,
-                    c->pj_ids.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p, c->ing_taps.p,
+                    c->match_q.p, c->match_t.p, c->match_o.p, c->pj_in.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p, c->pj_cells.p,
+                    c->pj_sorted.p, c->ing_taps.p,
                     c->ing_bgr.p, c->map_xyz, c->rp_uv_all.p, c->rp_mask.p, c->rp_off.p, c->rp_total.p,
                     c->vis_uv.p, c->vis_idx.p, c->tri_in.p, c->tri_out.p};
     for (void* b : bufs)
@@ -556,6 +559,7 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     c->max_kp = p.max_keypoints;
     c->nslots = p.frame_slots;
     c->slot_handle.assign((size_t)c->nslots, 0);
+    c->slot_count_host.assign((size_t)c->nslots, -1);
     *out = c; // returned even on failure so that slamfe_last_error can be read
     if (p.stream) {
         c->stream = (hipStream_t)p.stream;
@@ -991,42 +995,50 @@ int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n
         for (int i = 0; i < n_inl; ++i) matched_point_id[i] = -1;
         return SLAMFE_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->kp_count + slot, sizeof(int32_t), hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int32_t nkp = c->h_cnt[0];
+    // the frame's keypoint count: known on the host if the frame came through a
+    // host-pointer call (its results were downloaded); else one read-back
+    int32_t nkp = c->slot_count_host[(size_t)slot];
+    if (nkp < 0) {
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->kp_count + slot, sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        nkp = c->h_cnt[0];
+        c->slot_count_host[(size_t)slot] = nkp;
+    }
     if (nkp > c->max_kp) nkp = c->max_kp;
     for (int i = 0; i < n_inl; ++i)
         if (kp_idx[i] < 0 || kp_idx[i] >= nkp)
             return fail(c, SLAMFE_E_INVALID, "kp_idx[%d] = %d outside the frame's %d keypoints", i,
                         kp_idx[i], nkp);
     int rc;
-    if ((rc = grow(c, c->pj_idx, (size_t)n_inl * 4))) return rc;
+    // inputs travel as one block: inlier indices, then (host-supplied visible set
+    // only) uv and ids -- one transfer instead of three
+    const size_t o_idx = 0, o_uv = align256((size_t)n_inl * 4), o_ids = o_uv + align256((size_t)R * 8),
+                 in_bytes = d_uv ? o_uv : o_ids + align256((size_t)R * 4);
+    if ((rc = grow(c, c->pj_in, in_bytes))) return rc;
     if ((rc = grow(c, c->pj_cand, (size_t)n_inl * SLAMFE_PROJ_K * 4))) return rc;
     if ((rc = grow(c, c->pj_candn, (size_t)n_inl * 4))) return rc;
     if ((rc = grow(c, c->pj_matched, (size_t)n_inl * 4))) return rc;
-    if (!d_uv) {
-        if ((rc = grow(c, c->pj_uv, (size_t)R * 8))) return rc;
-        if ((rc = grow(c, c->pj_ids, (size_t)R * 4))) return rc;
-    }
+    if ((rc = grow(c, c->pj_cells, slamfe_projection_grid_bytes()))) return rc;
+    if ((rc = grow(c, c->pj_sorted, (size_t)R * 16))) return rc;
     hipStream_t s = c->stream;
-    const size_t o_idx = 0, o_uv = align256((size_t)n_inl * 4), o_ids = o_uv + align256((size_t)R * 8),
-                 o_out = o_ids + align256((size_t)R * 4);
+    const size_t o_out = in_bytes;
     if ((rc = pin_reserve(c, o_out + (size_t)n_inl * 4))) return rc;
+    HIPCHK(c, hipStreamSynchronize(s)); // the bounce buffer may still be in use
     memcpy(c->h_pin + o_idx, kp_idx, (size_t)n_inl * 4);
-    HIPCHK(c, hipMemcpyAsync(c->pj_idx.p, c->h_pin + o_idx, (size_t)n_inl * 4, hipMemcpyHostToDevice, s));
     if (!d_uv) {
         memcpy(c->h_pin + o_uv, uv, (size_t)R * 8);
         memcpy(c->h_pin + o_ids, point_ids, (size_t)R * 4);
-        HIPCHK(c, hipMemcpyAsync(c->pj_uv.p, c->h_pin + o_uv, (size_t)R * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->pj_ids.p, c->h_pin + o_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
-        d_uv = (const float*)c->pj_uv.p;
-        d_ids = (const int32_t*)c->pj_ids.p;
+        d_uv = (const float*)((const uint8_t*)c->pj_in.p + o_uv);
+        d_ids = (const int32_t*)((const uint8_t*)c->pj_in.p + o_ids);
     }
+    HIPCHK(c, hipMemcpyAsync(c->pj_in.p, c->h_pin, in_bytes, hipMemcpyHostToDevice, s));
+    const int32_t* d_idx = (const int32_t*)c->pj_in.p;
     KCHK(c, slamfe_launch_projection(s, c->kps + (size_t)slot * c->max_kp,
                                      c->desc + (size_t)slot * c->max_kp * 32, nkp,
-                                     (const int32_t*)c->pj_idx.p, n_inl, d_uv, d_ids, R, c->map_desc,
-                                     radius, max_hamming, (uint32_t*)c->pj_cand.p,
+                                     d_idx, n_inl, d_uv, d_ids, R, c->map_desc,
+                                     radius, max_hamming, c->p.max_width, c->p.max_height,
+                                     (uint32_t*)c->pj_cells.p, c->pj_sorted.p, (uint32_t*)c->pj_cand.p,
                                      (int32_t*)c->pj_candn.p, (int32_t*)c->pj_matched.p));
     HIPCHK(c, hipMemcpyAsync(c->h_pin + o_out, c->pj_matched.p, (size_t)n_inl * 4,
                              hipMemcpyDeviceToHost, s));

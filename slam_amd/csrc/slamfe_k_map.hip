@@ -4,18 +4,23 @@
 // ---------------------------------------------------------------------------
 // K9  search by projection (Init.cc:229-259).
 //
-// Pass 1 (parallel, one workgroup per inlier): test every visible map point
-// against the inlier's keypoint -- pixel distance gate first (Init.cc:389-391
+// Pass 0 (one workgroup): bucket the visible points into a uniform grid whose
+// cells are at least one search radius wide: count per cell, prefix sum,
+// scatter of {u, v, position, point id} records into cell order.
+// Pass 1 (parallel, one wavefront per inlier): test the points of the 3 x 3
+// cells around the inlier's keypoint -- pixel distance gate first (Init.cc:389-391
 // arithmetic: float differences, double squares and sqrt, narrowed to float),
 // then Hamming distance against the device-resident map descriptor row -- and
 // keep the PROJ_K best candidates as keys (hamming << 20 | position), sorted.
+// The keys carry the point's position in the caller's (ascending) list, so the
+// order of the records inside a cell does not matter.
 // Pass 2 (one wavefront, in inlier order): take the first candidate not yet
 // consumed; that is exactly the reference's "minimum over the remaining
 // points, then erase".  An inlier whose list overflowed and ran dry is
 // re-scanned against all points by the whole wave.
 // ---------------------------------------------------------------------------
 #define PROJ_K 32
-#define PROJ_LDS 2048
+#define PROJ_GRID_MAX 128   /* cells per axis */
 
 // The pixel-distance gate of Init.cc:389-391 and Init.cc:242: float differences,
 // squares and sum in double, square root narrowed to float, compared with the
@@ -30,71 +35,297 @@ __device__ __forceinline__ bool proj_gate(float ux, float uy, float kx, float ky
     return dd <= gate_dd;
 }
 
+// Grid over the projected points.  A coordinate's cell is
+// clamp(floor(x / cell), 0, n - 1): the clamp is monotone and never widens a
+// difference, so two positions no further apart than one cell width (>= the
+// radius with a margin far above the rounding of the division) land in the same
+// or in adjacent cells, whatever their values -- points outside the image, at
+// infinity or NaN included (NaN goes to cell 0 and never passes the gate).
+struct slamfe_proj_grid {
+    double inv_cell;
+    int gx, gy;
+};
 
-__global__ __launch_bounds__(256) void k_proj_candidates(
-    const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
-    const int32_t* __restrict__ kp_idx, int n_inl, const float2* __restrict__ uv,
-    const int32_t* __restrict__ point_ids, int R, const uint32_t* __restrict__ map_desc,
-    double gate_dd, int max_hamming, uint32_t* __restrict__ cand_out, int32_t* __restrict__ cand_n)
+__device__ __forceinline__ int proj_cell_coord(float x, double inv_cell, int n)
 {
-    __shared__ uint32_t lds[PROJ_LDS];
-    __shared__ uint32_t cnt;
-    const int i = blockIdx.x, tid = threadIdx.x;
-    const int idx = kp_idx[i];
-    if (tid == 0) cnt = 0;
+    const double c = floor((double)x * inv_cell);
+    return (int)fmin(fmax(c, 0.0), (double)(n - 1)); // fmax(NaN, 0) = 0
+}
+
+// One workgroup builds the whole grid in LDS: the work is a few loads and LDS
+// atomics per point, far too little for a multi-kernel count / scan / scatter.
+// Its time is the LDS atomics (points cluster, so many lanes hit one counter
+// and are served one after the other) and the memory latency of the one CU
+// that runs it.  So a thread fetches its points in batches of independent
+// loads, and where they fit in registers (R <= 1024 * PROJ_GRID_KEEP) the count
+// pass's atomics return the point's rank inside its cell, which makes the
+// scatter pass atomic-free: position = cell start + rank.
+#define PROJ_GRID_KEEP 20
+#define PROJ_GRID_BATCH 8
+__global__ __launch_bounds__(1024) void k_proj_grid(const float2* __restrict__ uv,
+                                                     const int32_t* __restrict__ point_ids, int R,
+                                                     slamfe_proj_grid G, uint32_t* __restrict__ cell_start,
+                                                     uint4* __restrict__ sorted)
+{
+    extern __shared__ uint32_t glds[]; // ncells counters (later: cell starts / fill cursors), then 16 wave totals
+    const int ncells = G.gx * G.gy;
+    uint32_t* cnt = glds;
+    uint32_t* wtot = glds + ncells;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool keep = R <= 1024 * PROJ_GRID_KEEP; // uniform
+    for (int c = tid; c < ncells; c += 1024) cnt[c] = 0;
     __syncthreads();
-    if (idx >= 0 && idx < nkp) {
-        const float kx = kps[idx].x, ky = kps[idx].y;
-        const uint32_t* qd = fdesc + (size_t)idx * 8;
-        // four positions per step so that the loads are in flight together
-        for (int j0 = tid; j0 < R; j0 += 4 * 256) {
-            float2 p[4];
+    float2 kp[PROJ_GRID_KEEP];
+    uint32_t kcr[PROJ_GRID_KEEP]; // cell << 16 | rank inside the cell (both below 2^16 on this path)
+    if (keep) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * 256;
+        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+            const int j = u * 1024 + tid;
+            kp[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+            const int j = u * 1024 + tid;
+            kcr[u] = 0;
+            if (j < R) {
+                const uint32_t cell = (uint32_t)(proj_cell_coord(kp[u].y, G.inv_cell, G.gy) * G.gx +
+                                                 proj_cell_coord(kp[u].x, G.inv_cell, G.gx));
+                kcr[u] = (cell << 16) | atomicAdd(&cnt[cell], 1u);
+            }
+        }
+    } else {
+        for (int base = 0; base < R; base += 1024 * PROJ_GRID_BATCH) {
+            float2 p[PROJ_GRID_BATCH];
+#pragma unroll
+            for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
+                const int j = base + u * 1024 + tid;
                 p[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * 256;
-                if (j < R && proj_gate(p[u].x, p[u].y, kx, ky, gate_dd)) {
-                    int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
-                    if (h <= max_hamming) {
-                        uint32_t pos = atomicAdd(&cnt, 1u);
-                        if (pos < PROJ_LDS) lds[pos] = ((uint32_t)h << 20) | (uint32_t)j;
-                    }
-                }
+            for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
+                const int j = base + u * 1024 + tid;
+                if (j < R)
+                    atomicAdd(&cnt[proj_cell_coord(p[u].y, G.inv_cell, G.gy) * G.gx +
+                                   proj_cell_coord(p[u].x, G.inv_cell, G.gx)], 1u);
             }
         }
     }
     __syncthreads();
-    const uint32_t n = cnt;
-    if (n > PROJ_LDS) { // too dense to rank here: leave it to the serial pass
-        if (tid == 0) cand_n[i] = -1;
+    // exclusive prefix sum over the cells: every thread owns a run of consecutive cells
+    const int per = (ncells + 1023) / 1024;
+    const int c0 = min(tid * per, ncells), c1 = min(c0 + per, ncells);
+    uint32_t sum = 0;
+    for (int c = c0; c < c1; ++c) sum += cnt[c];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t before = incl - sum;
+    for (int k = 0; k < wv; ++k) before += wtot[k];
+    for (int c = c0; c < c1; ++c) {
+        const uint32_t n = cnt[c];
+        cnt[c] = before; // from here on: the cell's start (and fill cursor on the reload path)
+        cell_start[c] = before;
+        before += n;
+    }
+    if (tid == 1023) cell_start[ncells] = before; // == R
+    __syncthreads();
+    if (keep) {
+        int32_t id[PROJ_GRID_KEEP];
+#pragma unroll
+        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+            const int j = u * 1024 + tid;
+            id[u] = j < R ? point_ids[j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+            const int j = u * 1024 + tid;
+            if (j < R)
+                sorted[cnt[kcr[u] >> 16] + (kcr[u] & 0xffffu)] =
+                    make_uint4(__float_as_uint(kp[u].x), __float_as_uint(kp[u].y), (uint32_t)j, (uint32_t)id[u]);
+        }
         return;
     }
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (uint32_t k = n + tid; k < np2; k += 256) lds[k] = 0xffffffffu;
-    __syncthreads();
-    for (uint32_t k = 2; k <= np2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t e = tid; e < np2; e += 256) {
-                uint32_t exj = e ^ j;
-                if (exj > e) {
-                    uint32_t a = lds[e], c = lds[exj];
-                    bool asc = (e & k) == 0;
-                    if ((a > c) == asc) {
-                        lds[e] = c;
-                        lds[exj] = a;
-                    }
-                }
-            }
-            __syncthreads();
+    for (int base = 0; base < R; base += 1024 * PROJ_GRID_BATCH) {
+        float2 p[PROJ_GRID_BATCH];
+        int32_t id[PROJ_GRID_BATCH];
+#pragma unroll
+        for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
+            const int j = base + u * 1024 + tid;
+            p[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
+            id[u] = j < R ? point_ids[j] : 0;
         }
-    if (tid < PROJ_K && tid < n) cand_out[(size_t)i * PROJ_K + tid] = lds[tid];
+#pragma unroll
+        for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
+            const int j = base + u * 1024 + tid;
+            if (j < R) {
+                const int cell = proj_cell_coord(p[u].y, G.inv_cell, G.gy) * G.gx +
+                                 proj_cell_coord(p[u].x, G.inv_cell, G.gx);
+                const uint32_t pos = atomicAdd(&cnt[cell], 1u);
+                sorted[pos] = make_uint4(__float_as_uint(p[u].x), __float_as_uint(p[u].y), (uint32_t)j,
+                                         (uint32_t)id[u]);
+            }
+        }
+    }
+}
+
+// Bitonic sort of 64 keys held one per lane, ascending by lane.
+__device__ __forceinline__ uint32_t proj_wave_sort64(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)v, j);
+            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+            v = keep_min ? min(v, o) : max(v, o);
+        }
+    return v;
+}
+
+// The points of the 3 x 3 cells around (kx, ky) as one index space: the three
+// cells of a grid row are neighbours in cell order, so a window is three ranges
+// of `sorted`.
+struct proj_window {
+    uint32_t beg[3], len[3], total;
+};
+
+__device__ __forceinline__ proj_window proj_window_of(float kx, float ky, const slamfe_proj_grid& G,
+                                                      const uint32_t* __restrict__ cell_start)
+{
+    const int cx = proj_cell_coord(kx, G.inv_cell, G.gx), cy = proj_cell_coord(ky, G.inv_cell, G.gy);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.gx - 1);
+    proj_window w;
+    w.total = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int yy = cy - 1 + d;
+        const bool in = yy >= 0 && yy < G.gy;
+        const int row = in ? yy : cy;
+        // (the keypoint is the wavefront's: make the range bounds scalar)
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell_start[row * G.gx + x0]);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell_start[row * G.gx + x1 + 1]);
+        w.beg[d] = b;
+        w.len[d] = in ? e - b : 0u;
+        w.total += w.len[d];
+    }
+    return w;
+}
+
+__device__ __forceinline__ uint32_t proj_window_at(const proj_window& w, uint32_t t)
+{
+    return t < w.len[0] ? w.beg[0] + t
+                        : (t < w.len[0] + w.len[1] ? w.beg[1] + (t - w.len[0])
+                                                   : w.beg[2] + (t - w.len[0] - w.len[1]));
+}
+
+__device__ __forceinline__ int proj_hamming(const uint32_t* __restrict__ row, const uint4& q0, const uint4& q1)
+{
+    const uint4* mp = reinterpret_cast<const uint4*>(row);
+    const uint4 a = mp[0], b = mp[1];
+    return __popc(a.x ^ q0.x) + __popc(a.y ^ q0.y) + __popc(a.z ^ q0.z) + __popc(a.w ^ q0.w) +
+           __popc(b.x ^ q1.x) + __popc(b.y ^ q1.y) + __popc(b.z ^ q1.z) + __popc(b.w ^ q1.w);
+}
+
+// Compare-exchange network that sorts a bitonic sequence of 64 keys (one per
+// lane) into ascending order.
+__device__ __forceinline__ uint32_t proj_wave_merge64(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, j);
+        v = (lane & j) == 0 ? min(v, o) : max(v, o);
+    }
+    return v;
+}
+
+// One wavefront per inlier, four per workgroup, no workgroup barriers.  The
+// window is walked PROJ_UNROLL x 64 records at a time so that the record loads
+// of a step, and then its descriptor-row loads, are in flight together (the
+// kernel is a chain of dependent loads).  The wave keeps the 64 smallest keys seen
+// so far sorted in registers, one per lane.  Keys that pass both gates and are
+// smaller than the current PROJ_K-th smallest wait in a 64-entry LDS buffer; a
+// full buffer is sorted (register bitonic network), laid against the kept keys in
+// opposite order -- the lane-wise minimum of an ascending and a descending run
+// holds the 64 smallest of both and is bitonic -- and merged.  Any number of
+// candidates is ranked this way; dense maps cost a few more merges.
+#define PROJ_UNROLL 4
+__global__ __launch_bounds__(256) void k_proj_candidates(
+    const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
+    const int32_t* __restrict__ kp_idx, int n_inl, slamfe_proj_grid G,
+    const uint32_t* __restrict__ cell_start, const uint4* __restrict__ sorted,
+    const uint32_t* __restrict__ map_desc, double gate_dd, int max_hamming,
+    uint32_t* __restrict__ cand_out, int32_t* __restrict__ cand_n)
+{
+    __shared__ uint32_t pending[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv);
+    if (i >= n_inl) return; // whole wavefronts leave; no workgroup barrier below
+    uint32_t* my = pending[wv];
+    const int idx = kp_idx[i];
+    if (idx < 0 || idx >= nkp) { // rejected by the host before the launch; never taken
+        if (lane == 0) cand_n[i] = 0;
+        return;
+    }
+    const float kx = kps[idx].x, ky = kps[idx].y;
+    const uint4* qp = reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 8);
+    const uint4 q0 = qp[0], q1 = qp[1];
+    const proj_window w = proj_window_of(kx, ky, G, cell_start);
+    uint32_t best = 0xffffffffu; // the 64 smallest keys so far, ascending over the lanes
+    uint32_t kth = 0xffffffffu;  // the PROJ_K-th smallest so far: larger keys cannot matter
+    uint32_t npend = 0, ntotal = 0; // keys waiting in LDS / keys that passed both gates (uniform)
+    auto flush = [&]() {
+        wave_lds_fence();
+        uint32_t v = (uint32_t)lane < npend ? my[lane] : 0xffffffffu;
+        v = proj_wave_sort64(v);
+        v = (uint32_t)__shfl((int)v, 63 - lane); // descending
+        best = proj_wave_merge64(min(best, v));
+        kth = (uint32_t)__builtin_amdgcn_readlane((int)best, PROJ_K - 1);
+        npend = 0;
+        wave_lds_fence();
+    };
+    for (uint32_t t0 = 0; t0 < w.total; t0 += 64 * PROJ_UNROLL) { // uniform
+        uint4 e[PROJ_UNROLL];
+        bool in[PROJ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PROJ_UNROLL; ++u) {
+            const uint32_t t = t0 + (uint32_t)(u * 64 + lane);
+            in[u] = t < w.total;
+            e[u] = make_uint4(0, 0, 0, 0);
+            if (in[u]) e[u] = sorted[proj_window_at(w, t)];
+        }
+        int h[PROJ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PROJ_UNROLL; ++u) {
+            h[u] = 1 << 10;
+            if (in[u] && proj_gate(__uint_as_float(e[u].x), __uint_as_float(e[u].y), kx, ky, gate_dd))
+                h[u] = proj_hamming(map_desc + (size_t)e[u].w * 8, q0, q1);
+        }
+#pragma unroll
+        for (int u = 0; u < PROJ_UNROLL; ++u) {
+            const bool pass = h[u] <= max_hamming;
+            ntotal += (uint32_t)__popcll(__ballot(pass));
+            const uint32_t key = ((uint32_t)h[u] << 20) | e[u].z;
+            const bool keep = pass && key < kth;
+            const unsigned long long m = __ballot(keep);
+            const uint32_t c = (uint32_t)__popcll(m);
+            if (c == 0) continue;         // uniform
+            if (npend + c > 64) flush();  // uniform; the keys of this step are compared with the old kth: harmless
+            if (keep) my[npend + lane_rank(m)] = key;
+            npend += c;
+        }
+    }
+    if (npend) flush();
+    if (lane < PROJ_K && best != 0xffffffffu) cand_out[(size_t)i * PROJ_K + lane] = best;
     // cand_n: number of stored candidates; bit 30 set if more passed the gates
-    if (tid == 0) cand_n[i] = (int32_t)(n < PROJ_K ? n : (PROJ_K | (n > PROJ_K ? (1 << 30) : 0)));
+    if (lane == 0)
+        cand_n[i] = (int32_t)(ntotal < PROJ_K ? ntotal : (PROJ_K | (ntotal > PROJ_K ? (1 << 30) : 0)));
 }
 
 #define PROJ_CHUNK 64 /* inliers per staged chunk */
@@ -103,10 +334,11 @@ __global__ __launch_bounds__(256) void k_proj_candidates(
 
 __global__ __launch_bounds__(256) void k_proj_resolve(
     const slamfe_keypoint* __restrict__ kps, const uint32_t* __restrict__ fdesc, int nkp,
-    const int32_t* __restrict__ kp_idx, int n_inl, const float2* __restrict__ uv,
-    const int32_t* __restrict__ point_ids, int R, const uint32_t* __restrict__ map_desc,
-    double gate_dd, int max_hamming, const uint32_t* __restrict__ cand,
-    const int32_t* __restrict__ cand_n, int32_t* __restrict__ matched)
+    const int32_t* __restrict__ kp_idx, int n_inl, const int32_t* __restrict__ point_ids, int R,
+    slamfe_proj_grid G, const uint32_t* __restrict__ cell_start, const uint4* __restrict__ sorted,
+    const uint32_t* __restrict__ map_desc, double gate_dd, int max_hamming,
+    const uint32_t* __restrict__ cand, const int32_t* __restrict__ cand_n,
+    int32_t* __restrict__ matched)
 {
     // One workgroup of four waves.  Wave 0 resolves the inliers in order, 64 at
     // a time; waves 1-3 meanwhile copy the next chunk of 64 candidate lists from
@@ -140,9 +372,28 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
         int32_t* sn = reinterpret_cast<int32_t*>(st + PROJ_CHUNK * PROJ_STRIDE);
         const int t = tid - t0;
         if (t < PROJ_CHUNK) sn[t] = t < nc ? cand_n[c0 + t] : 0;
-        const uint32_t* src = cand + (size_t)c0 * PROJ_K;
-#pragma unroll 4
-        for (int e = t; e < nc * PROJ_K; e += nt) st[(e / PROJ_K) * PROJ_STRIDE + (e % PROJ_K)] = src[e];
+        // 16-byte pieces, all of a thread's loads issued before the first store: the
+        // copy is one memory latency, not one per piece
+        const uint4* src = reinterpret_cast<const uint4*>(cand + (size_t)c0 * PROJ_K);
+        constexpr int PIECES = PROJ_CHUNK * PROJ_K / 4; // 512
+        uint4 v[(PIECES + 191) / 192];
+#pragma unroll
+        for (int u = 0; u < (PIECES + 191) / 192; ++u) {
+            const int e = t + u * nt;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (u * nt < PIECES && e < nc * (PROJ_K / 4)) v[u] = src[e];
+        }
+#pragma unroll
+        for (int u = 0; u < (PIECES + 191) / 192; ++u) {
+            const int e = t + u * nt;
+            if (u * nt < PIECES && e < nc * (PROJ_K / 4)) {
+                uint32_t* d = st + (e / (PROJ_K / 4)) * PROJ_STRIDE + (e % (PROJ_K / 4)) * 4;
+                d[0] = v[u].x;
+                d[1] = v[u].y;
+                d[2] = v[u].z;
+                d[3] = v[u].w;
+            }
+        }
     };
 
     load_chunk(0, 0, 0, 256);
@@ -168,7 +419,9 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
             const uint32_t* mylist = stage + lane * PROJ_STRIDE;
             int pos = 0, result = -1;
             bool done = lane >= nc;
-            while (__ballot(!done)) { // every round finishes at least the first open lane
+            // every round finishes at least the first open lane, so 64 rounds always
+            // suffice; the bound makes the exit unconditional
+            while (__ballot(!done) && round < 2 * PROJ_CHUNK) {
                 int prop = -1; // position j of the proposed point
                 bool dry = false;
                 if (!done) {
@@ -183,15 +436,17 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
                     dry = prop < 0 && overflow; // the stored list ran out but more candidates exist
                 }
                 // Did an earlier open lane propose the same point?  Every proposal is
-                // entered in a hash table with atomicMax on (round, 63 - lane, point):
+                // entered in a hash table with atomicMax on (round, 63 - lane, point)
+                // -- 7 + 6 + 19 bits: a chunk can take 64 rounds (one lane finishing per
+                // round), positions stay below SLAMFE_PROJ_MAX_POINTS = 2^19 --:
                 // the current round beats stale entries, the lowest lane wins its
                 // slot, and a lane that does not find its own entry stops.  Two
                 // different points in one slot stop the later lane needlessly, which
                 // only shortens this round's prefix.
-                ++round; // at most 64 rounds per chunk: each one finishes a lane
+                ++round; // 1 .. 64 (7 bits in the claim key)
                 bool stop = dry;
                 if (prop >= 0) {
-                    const uint32_t mine = (round << 26) | ((uint32_t)(63 - lane) << 20) | (uint32_t)prop;
+                    const uint32_t mine = (round << 25) | ((uint32_t)(63 - lane) << 19) | (uint32_t)prop;
                     const uint32_t slot = ((uint32_t)prop * 2654435761u) >> 20; // 12 bits
                     atomicMax(&claim[slot], mine);
                     wave_lds_fence();
@@ -207,19 +462,23 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
                     done = true;
                 }
                 if (k < 64 && __builtin_amdgcn_readlane((int)dry, k)) { // uniform
-                    // inlier k has to look at every point again: the whole wave does it
+                    // inlier k has to look at the points around it again (the 3 x 3 cells
+                    // of its keypoint): the whole wave does it
                     const int i = c0 + k;
                     const int idx = kp_idx[i];
                     uint32_t best = 0xffffffffu;
                     if (idx >= 0 && idx < nkp) {
                         const float kx = kps[idx].x, ky = kps[idx].y;
-                        const uint32_t* qd = fdesc + (size_t)idx * 8;
-                        for (int j = lane; j < R; j += 64) {
+                        const uint4* qp = reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 8);
+                        const uint4 q0 = qp[0], q1 = qp[1];
+                        const proj_window w = proj_window_of(kx, ky, G, cell_start);
+                        for (uint32_t t = (uint32_t)lane; t < w.total; t += 64) {
+                            const uint4 e = sorted[proj_window_at(w, t)];
+                            const uint32_t j = e.z;
                             if ((vt[j >> 5] >> (j & 31)) & 1u) continue;
-                            float2 p = uv[j];
-                            if (!proj_gate(p.x, p.y, kx, ky, gate_dd)) continue;
-                            int h = hamming256_dev(map_desc + (size_t)point_ids[j] * 8, qd);
-                            if (h <= max_hamming) best = min(best, ((uint32_t)h << 20) | (uint32_t)j);
+                            if (!proj_gate(__uint_as_float(e.x), __uint_as_float(e.y), kx, ky, gate_dd)) continue;
+                            const int h = proj_hamming(map_desc + (size_t)e.w * 8, q0, q1);
+                            if (h <= max_hamming) best = min(best, ((uint32_t)h << 20) | j);
                         }
                     }
 #pragma unroll
@@ -270,24 +529,55 @@ double slamfe_proj_gate_threshold(float radius)
     return dd;
 }
 
+// Cell width and grid size for a search radius on frames of at most max_w x max_h
+// pixels: cells a little wider than the radius (the margin of 1e-4 dwarfs the
+// float rounding of the gate and of the cell division), at most PROJ_GRID_MAX
+// cells per axis.
+static slamfe_proj_grid proj_grid_for(float radius, int max_w, int max_h)
+{
+    double r = radius > 0.f ? (double)radius : 0.0; // negative / NaN radius: nothing passes anyway
+    const double maxdim = (double)(max_w > max_h ? max_w : max_h);
+    double cell = r * 1.0001 + 1e-3;
+    if (cell < maxdim / PROJ_GRID_MAX) cell = maxdim / PROJ_GRID_MAX;
+    slamfe_proj_grid G;
+    G.inv_cell = 1.0 / cell; // 0 for an infinite radius: one cell
+    auto cells = [&](int dim) {
+        double n = floor((double)dim * G.inv_cell) + 1.0;
+        return (int)(n < 1.0 ? 1.0 : (n > PROJ_GRID_MAX ? (double)PROJ_GRID_MAX : n));
+    };
+    G.gx = cells(max_w);
+    G.gy = cells(max_h);
+    return G;
+}
+
+size_t slamfe_projection_grid_bytes(void) { return ((size_t)PROJ_GRID_MAX * PROJ_GRID_MAX + 1) * sizeof(uint32_t); }
+
 int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
                              const int32_t* kp_idx, int n_inl, const float* uv,
                              const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
-                             int max_hamming, uint32_t* cand, int32_t* cand_n, int32_t* matched)
+                             int max_hamming, int max_w, int max_h, uint32_t* cell_start, void* sorted,
+                             uint32_t* cand, int32_t* cand_n, int32_t* matched)
 {
     if (n_inl <= 0) return 0;
     const double gate_dd = slamfe_proj_gate_threshold(radius);
-    hipLaunchKernelGGL(k_proj_candidates, dim3(n_inl), dim3(256), 0, s, kps,
-                       reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
-                       reinterpret_cast<const float2*>(uv), point_ids, R,
-                       reinterpret_cast<const uint32_t*>(map_desc), gate_dd, max_hamming, cand, cand_n);
+    if (max_hamming > 256) max_hamming = 256; // no two rows are further apart
+    const slamfe_proj_grid G = proj_grid_for(radius, max_w, max_h);
+    const int ncells = G.gx * G.gy;
+    hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(1024), ((size_t)ncells + 16) * sizeof(uint32_t), s,
+                       reinterpret_cast<const float2*>(uv), point_ids, R, G, cell_start,
+                       reinterpret_cast<uint4*>(sorted));
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_proj_candidates, dim3((n_inl + 3) / 4), dim3(256), 0, s, kps,
+                       reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl, G, cell_start,
+                       reinterpret_cast<const uint4*>(sorted), reinterpret_cast<const uint32_t*>(map_desc),
+                       gate_dd, max_hamming, cand, cand_n);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(256),
                        (2 * (PROJ_CHUNK * PROJ_STRIDE + PROJ_CHUNK) + PROJ_CHUNK + 2 * PROJ_CLAIM) * 4 +
                            ((size_t)R + 31) / 32 * 4 + 4,
                        s, kps,
-                       reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl,
-                       reinterpret_cast<const float2*>(uv), point_ids, R,
+                       reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl, point_ids, R, G,
+                       cell_start, reinterpret_cast<const uint4*>(sorted),
                        reinterpret_cast<const uint32_t*>(map_desc), gate_dd, max_hamming, cand, cand_n,
                        matched);
     LAUNCH_CHECK();
@@ -445,6 +735,11 @@ int slamfe_launch_triangulate(hipStream_t s, const float* P1, const float* P2, c
 // 64 KiB of dynamic LDS (very large local maps).
 int slamfe_projection_init(void)
 {
+    // the grid kernel's cell counters: up to PROJ_GRID_MAX^2 + 16 words
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_grid),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (PROJ_GRID_MAX * PROJ_GRID_MAX + 16) * 4);
+    if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SLAMFE_PROJ_MAX_POINTS / 8 +

@@ -51,7 +51,10 @@ int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int ns
 int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
                              const int32_t* kp_idx, int n_inl, const float* uv,
                              const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
-                             int max_hamming, uint32_t* cand, int32_t* cand_n, int32_t* matched);
+                             int max_hamming, int max_w, int max_h, uint32_t* cell_start /* grid_bytes */,
+                             void* sorted /* R * 16 bytes */, uint32_t* cand, int32_t* cand_n,
+                             int32_t* matched);
+size_t slamfe_projection_grid_bytes(void);
 int slamfe_launch_reproject(hipStream_t s, const float* xyz, int npoints, const float* M16, float th,
                             float W, float H, float* uv_all, uint64_t* wave_mask, int32_t* wave_off,
                             int32_t* total, float* vis_uv, int32_t* vis_idx);

@@ -423,6 +423,81 @@ def test_search_by_projection_dense_cluster(fe_orb):
     assert (got >= 0).sum() >= 100
 
 
+def _claim_slot(j):
+    # the hash slot k_proj_resolve enters a proposed position in
+    return ((int(j) * 2654435761) & 0xffffffff) >> 20
+
+
+@pytest.mark.parametrize("nA,nB", [(32, 32), (40, 0), (32, 31), (64, 0), (1, 63)])
+def test_search_by_projection_serial_chain_of_64(fe_orb, nA, nB):
+    # A chunk of 64 inliers that resolves one lane per round, 64 rounds: 32 inliers
+    # on keypoint A contest A's candidates one after the other, then 32 inliers on
+    # keypoint B do the same with B's.  The last proposal (round 64) goes to a
+    # hash slot that still holds a proposal of round 1.  Lists longer than the 32
+    # stored candidates (nA = 40, 64) run dry and are re-scanned.
+    img = synth.textured_canvas(640, 480, 57)
+    f = fe_orb.extract_keypoints(img)
+    xy = f.pt
+    kA = 5
+    far = np.nonzero(np.hypot(xy[:, 0] - xy[kA, 0], xy[:, 1] - xy[kA, 1]) > 150)[0]
+    kB = int(far[0])
+    R = 30000
+    uv = np.stack([3000 + np.arange(R, dtype=np.float32), np.full(R, 3000, np.float32)], 1)  # filler, far away
+    desc = synth.random_descriptors(R, 23, 2)
+    a_idx = [100 + 3 * t for t in range(nA)]
+    last = next(j for j in range(2000, R) if _claim_slot(j) == _claim_slot(a_idx[0]))
+    b_idx = [1000 + 5 * t for t in range(max(nB - 1, 0))] + ([last] if nB else [])
+    for k, idxs in ((kA, a_idx), (kB, b_idx)):
+        bits = np.unpackbits(f.descriptors[k], bitorder="little")
+        for t, j in enumerate(idxs):
+            b = bits.copy()
+            b[:t] ^= 1  # candidate t lies t bits away: the list order is the order of idxs
+            desc[j] = np.packbits(b, bitorder="little")
+            uv[j] = xy[k] + np.array([(t % 7) - 3, (t % 5) - 2], np.float32)
+    ids = np.arange(R, dtype=np.int32)
+    fe_orb.map_put(ids, desc)
+    inl = np.array([kA] * 32 + [kB] * 32, np.int32)
+    got = fe_orb.search_by_projection(f, inl, uv, ids)
+    want = O.search_by_projection(xy, f.descriptors, inl, uv, desc, ids)
+    assert np.array_equal(got, want)
+    assert list(got[:min(nA, 32)]) == a_idx[:32] and list(got[32:32 + nB]) == b_idx[:32]
+    # the same chain not aligned with a chunk of 64: 10 unrelated inliers in front
+    pre = np.arange(20, 30, dtype=np.int32)
+    inl2 = np.concatenate([pre, inl])
+    assert np.array_equal(fe_orb.search_by_projection(f, inl2, uv, ids),
+                          O.search_by_projection(xy, f.descriptors, inl2, uv, desc, ids))
+
+
+def test_search_by_projection_points_outside_the_image(fe_orb):
+    # projected positions outside the frame, far away, infinite and NaN: they fall
+    # into the clamped border cells of the grid and are judged by the gate alone
+    img = synth.textured_canvas(640, 480, 58)
+    f = fe_orb.extract_keypoints(img)
+    xy = f.pt
+    order = np.argsort(xy[:, 0] + xy[:, 1])
+    corner = order[:40]  # keypoints nearest the top-left corner ...
+    other = np.argsort(-(xy[:, 0] + xy[:, 1]))[:40]  # ... and the bottom-right one
+    ks = np.concatenate([corner, other])
+    n = len(ks)
+    uv = np.empty((4 * n, 2), np.float32)
+    desc = np.empty((4 * n, 32), np.uint8)
+    for i, k in enumerate(ks):
+        sgn = -1.0 if i < 40 else 1.0
+        uv[4 * i] = xy[k] + sgn * np.array([60.0, 45.0], np.float32)      # within 80 px, outside the image
+        uv[4 * i + 1] = xy[k] + sgn * np.array([79.0, 15.0], np.float32)  # just outside the radius
+        uv[4 * i + 2] = [np.inf, xy[k][1]] if i % 2 else [np.nan, np.nan]
+        uv[4 * i + 3] = sgn * np.array([1e30, -1e30], np.float32)
+        desc[4 * i:4 * i + 4] = f.descriptors[k]
+    assert (uv[0::4] < 0).any() and (uv[0::4, 0] > 640).any()
+    ids = np.arange(4 * n, dtype=np.int32)
+    fe_orb.map_put(ids, desc)
+    inl = ks.astype(np.int32)
+    got = fe_orb.search_by_projection(f, inl, uv, ids, radius=80.0)
+    want = O.search_by_projection(xy, f.descriptors, inl, uv, desc, ids, radius=80.0)
+    assert np.array_equal(got, want)
+    assert (got >= 0).sum() >= n // 2
+
+
 @pytest.mark.parametrize("w,h,n,seed", [(1241, 376, 20000, 7), (640, 480, 3000, 8), (640, 480, 1, 9),
                                         (640, 480, 257, 10)])
 def test_reproject_map_points(fe_orb, w, h, n, seed):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Call time of slamfe_search_by_projection: BASELINE config 2 (1241x376, 3000
+features, 20 000 map points) and the largest visible set a call accepts (2^19
+points), host arrays in / ids out.  Prints one JSON object per case, with the
+number of gate tests the 3x3-cell window query makes next to the brute-force
+pair count."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from slam_amd import abi, synth  # noqa: E402
+from slam_amd.frontend import FrontEnd  # noqa: E402
+
+
+def window_tests(xy, uv, radius, max_w, max_h):
+    """Gate tests of the grid query: points in the 3x3 cells around each keypoint."""
+    cell = max(radius * 1.0001 + 1e-3, max(max_w, max_h) / 128.0)
+    gx = int(min(128, np.floor(max_w / cell) + 1))
+    gy = int(min(128, np.floor(max_h / cell) + 1))
+    cx = np.clip(np.floor(uv[:, 0].astype(np.float64) / cell), 0, gx - 1).astype(np.int64)
+    cy = np.clip(np.floor(uv[:, 1].astype(np.float64) / cell), 0, gy - 1).astype(np.int64)
+    cnt = np.zeros((gy + 2, gx + 2), np.int64)
+    np.add.at(cnt, (cy + 1, cx + 1), 1)
+    win = sum(cnt[1 + dy:gy + 1 + dy, 1 + dx:gx + 1 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+    kx = np.clip(np.floor(xy[:, 0].astype(np.float64) / cell), 0, gx - 1).astype(np.int64)
+    ky = np.clip(np.floor(xy[:, 1].astype(np.float64) / cell), 0, gy - 1).astype(np.int64)
+    return int(win[ky, kx].sum())
+
+
+def case(npts, ninl_cap, reps):
+    w, h, nfeat = 1241, 376, 3000
+    frames = synth.frame_stream(w, h, 2, seed=9)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=nfeat, max_width=w, max_height=h,
+                  max_batch=2, map_capacity=npts) as fe:
+        f0, f1 = fe.extract_batch(list(frames))
+        m = fe.knn_match_frames(f0, f1)
+        uv, pdesc = synth.local_map(f1.descriptors, f1.pt, npts, w, h, seed=11)
+        ids = np.arange(npts, dtype=np.int32)
+        fe.map_put(ids, pdesc)
+        inl = m["idx0"][m["ratio_pass"] == 1].astype(np.int32)[:ninl_cap]
+        matched = np.zeros(len(inl), np.int32)
+
+        def search():
+            rc = fe._lib.slamfe_search_by_projection(fe._ctx, C.c_uint64(f1.handle), inl.ctypes.data, len(inl),
+                                                     uv.ctypes.data, ids.ctypes.data, npts, C.c_float(32.0), 128,
+                                                     matched.ctypes.data)
+            assert rc == 0, rc
+        for _ in range(3):
+            search()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            search()
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        tests = window_tests(f1.pt[inl], uv, 32.0, w, h)
+        return {"visible_points": npts, "inliers": int(len(inl)), "matched": int((matched >= 0).sum()),
+                "call_ms": round(t * 1e3, 4), "brute_force_pairs": int(len(inl)) * npts,
+                "window_gate_tests": tests, "gate_tests_per_s": round(tests / t, 1),
+                "brute_force_pairs_per_s_equivalent": round(len(inl) * npts / t, 1)}
+
+
+if __name__ == "__main__":
+    # usage: time_projection.py [visible_points [max_inliers [reps]]] (default: config 2, then a dense map)
+    if len(sys.argv) > 1:
+        a = [int(x) for x in sys.argv[1:]] + [100000, 20][len(sys.argv) - 2:]
+        print(json.dumps(case(a[0], a[1], a[2])))
+    else:
+        print(json.dumps(case(20000, 100000, 50)))
+        print(json.dumps(case(1 << 17, 200, 5)))
