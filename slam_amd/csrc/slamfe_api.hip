@@ -31,6 +31,9 @@
 #include "slamfe_kernels.h"
 #include "slamfe_math.h"
 
+// Calls with fewer frames than this take the fused, launch-poor kernels.
+#define SLAMFE_FEW_FRAMES 8
+
 namespace {
 
 struct Scratch {
@@ -229,6 +232,79 @@ void resize_taps(int ssize, int dsize, uint32_t* out)
     }
 }
 
+// Range tables of the one-launch pyramid kernel.  Level 0 is cut into tiles of
+// SLAMFE_PT_W x SLAMFE_PT_H pixels; tile t owns, on every level l, the columns
+// [own0, own1) with own0 = floor(t * PT_W * w_l / w_0) rounded down to a multiple
+// of 4 (a partition of the level; dword stores of neighbouring tiles never
+// overlap) and has to compute the columns [need0, need1): its own ones plus
+// whatever the taps of its needed columns on level l + 1 read.  Rows likewise
+// (no rounding).  Entry (l, t) of a table is two words: need0 | need1 << 16,
+// own0 | own1 << 16.  Appended to the tap buffer; sets g->pt_* (pt_x = 0 if
+// the kernel's LDS budget does not hold the largest tile).
+void build_fused_pyramid_tables(slamfe_dev_geom* g, std::vector<uint32_t>* taps)
+{
+    g->pt_x = g->pt_y = 0;
+    g->pt_lds = 0;
+    const int L = g->nlevels;
+    if (L < 2) return;
+    for (int l = 0; l < L; ++l)
+        if (g->lv[l].w < 1 || g->lv[l].h < 1) return;
+    const int ntx = (g->lv[0].w + SLAMFE_PT_W - 1) / SLAMFE_PT_W, nty = (g->lv[0].h + SLAMFE_PT_H - 1) / SLAMFE_PT_H;
+    size_t max_need[2][SLAMFE_MAX_LEVELS] = {};
+    std::vector<uint32_t> tab[2];
+    for (int axis = 0; axis < 2; ++axis) {
+        const int nt = axis ? nty : ntx, tile = axis ? SLAMFE_PT_H : SLAMFE_PT_W;
+        tab[axis].assign((size_t)L * nt * 2, 0u);
+        for (int t = 0; t < nt; ++t) {
+            int need0[SLAMFE_MAX_LEVELS], need1[SLAMFE_MAX_LEVELS];
+            for (int l = L - 1; l >= 0; --l) {
+                const int dim = axis ? g->lv[l].h : g->lv[l].w, dim0 = axis ? g->lv[0].h : g->lv[0].w;
+                auto cut = [&](int k) {
+                    if (k >= nt) return dim;
+                    long long v = (long long)k * tile * dim / dim0;
+                    if (!axis) v &= ~3LL;
+                    return (int)(v > dim ? dim : v);
+                };
+                const int own0 = cut(t), own1 = cut(t + 1);
+                int n0 = own0, n1 = own1;
+                if (l + 1 < L && need1[l + 1] > need0[l + 1]) {
+                    const uint32_t* tp = taps->data() + (axis ? g->lv[l + 1].tap_y : g->lv[l + 1].tap_x);
+                    const uint32_t a = tp[need0[l + 1]], b = tp[need1[l + 1] - 1];
+                    int s0 = (int)(a & 0xffffu), s1 = (int)(b & 0xffffu) + ((b >> 16) ? 1 : 0) + 1;
+                    if (s1 > dim) s1 = dim;
+                    if (n1 <= n0) { n0 = s0; n1 = s1; }
+                    else { n0 = std::min(n0, s0); n1 = std::max(n1, s1); }
+                }
+                need0[l] = n0;
+                need1[l] = n1;
+                tab[axis][((size_t)l * nt + t) * 2] = (uint32_t)n0 | ((uint32_t)n1 << 16);
+                tab[axis][((size_t)l * nt + t) * 2 + 1] = (uint32_t)own0 | ((uint32_t)own1 << 16);
+                max_need[axis][l] = std::max(max_need[axis][l], (size_t)(n1 > n0 ? n1 - n0 : 0));
+            }
+        }
+    }
+    // LDS: 64 words of ranges, the tap cache, two level buffers (even / odd levels)
+    size_t tapc = 0, buf[2] = {0, 0};
+    for (int l = 0; l < L; ++l) {
+        if (l > 0) tapc += max_need[0][l] + max_need[1][l];
+        const size_t pitch = (max_need[0][l] + 3) / 4 * 4 + 4;
+        buf[l & 1] = std::max(buf[l & 1], pitch * max_need[1][l]);
+    }
+    const size_t off_taps = 64 * 4, off_a = off_taps + tapc * 4, off_b = off_a + (buf[0] + 15) / 16 * 16,
+                 total = off_b + (buf[1] + 15) / 16 * 16;
+    if (total > SLAMFE_PT_LDS_MAX) return;
+    g->ptab_x = (uint32_t)taps->size();
+    taps->insert(taps->end(), tab[0].begin(), tab[0].end());
+    g->ptab_y = (uint32_t)taps->size();
+    taps->insert(taps->end(), tab[1].begin(), tab[1].end());
+    g->pt_x = ntx;
+    g->pt_y = nty;
+    g->pt_lds = (uint32_t)total;
+    g->pt_off_taps = (uint32_t)off_taps;
+    g->pt_off_a = (uint32_t)off_a;
+    g->pt_off_b = (uint32_t)off_b;
+}
+
 // Level sizes, scales and retain-best quotas as cv::ORB computes them
 // (Init.cc:65: nfeatures, 1.2f, 8 levels), plus the device layout.
 void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
@@ -292,6 +368,7 @@ void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
             resize_taps(g->lv[l - 1].w, g->lv[l].w, taps->data() + g->lv[l].tap_x);
             resize_taps(g->lv[l - 1].h, g->lv[l].h, taps->data() + g->lv[l].tap_y);
         }
+        build_fused_pyramid_tables(g, taps);
     }
 }
 
@@ -362,10 +439,17 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     }
     c->next_seq += (uint64_t)n;
 
-    if (d_imgs)
-        KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
-                                     g.frame_bytes, g.lv[0].pitch));
-    {
+    // Calls of a few frames are bound by the chain of dependent launches, not by
+    // the arithmetic: they take the fused kernels (fewer launches, some redundant
+    // work); batches take the throughput kernels.  Results are identical.
+    const bool few = n < SLAMFE_FEW_FRAMES;
+    if (few && g.pt_x > 0) {
+        ProbeScope ps(c, SLAMFE_STAGE_PYRAMID);
+        KCHK(c, slamfe_launch_pyramid_fused(s, g, n, d_imgs, stride, frame_stride, channels, c->pyr, c->taps));
+    } else {
+        if (d_imgs)
+            KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
+                                         g.frame_bytes, g.lv[0].pitch));
         ProbeScope ps(c, SLAMFE_STAGE_PYRAMID);
         KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
     }
@@ -577,7 +661,11 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     c->cap_frame_bytes = (size_t)gmax.frame_bytes + 4096;
     c->cap_tiles = gmax.total_tiles + 2 * SLAMFE_MAX_LEVELS + 64;
     c->cap_bands = gmax.total_bands + SLAMFE_MAX_LEVELS;
-    c->cap_taps = tmax.size() + 64;
+    // (the range tables of the one-launch pyramid are part of this buffer: room
+    // for the largest number of tiles whether or not the maximum size uses them)
+    c->cap_taps = tmax.size() + 64 +
+                  (size_t)SLAMFE_MAX_LEVELS * 2 *
+                      ((p.max_width + SLAMFE_PT_W - 1) / SLAMFE_PT_W + (p.max_height + SLAMFE_PT_H - 1) / SLAMFE_PT_H + 2);
     KCHK(c, slamfe_kernels_init(sort_lds_bytes_for(gmax)));
 
     const size_t B = (size_t)p.max_batch;

@@ -38,8 +38,18 @@ typedef struct slamfe_dev_geom {
     int32_t total_bands;
     int32_t total_groups;
     uint32_t frame_bytes; /* bytes of one frame's pyramid */
+    /* one-launch pyramid (k_pyramid_fused): level-0 tiles of SLAMFE_PT_W x SLAMFE_PT_H
+     * pixels; pt_x = 0 if the geometry does not fit its LDS budget */
+    int32_t pt_x, pt_y;        /* tiles per axis */
+    uint32_t ptab_x, ptab_y;   /* offsets (uint32 entries) of its range tables in the tap buffer */
+    uint32_t pt_lds;           /* dynamic LDS bytes */
+    uint32_t pt_off_taps, pt_off_a, pt_off_b; /* byte offsets inside that LDS: tap cache, the two level buffers */
     slamfe_dev_level lv[SLAMFE_MAX_LEVELS];
 } slamfe_dev_geom;
+
+#define SLAMFE_PT_W 128
+#define SLAMFE_PT_H 32
+#define SLAMFE_PT_LDS_MAX (96 * 1024)
 
 /* Candidate / keypoint key: y in bits 31..20, x in bits 19..8, score in 7..0,
  * so ascending keys are in (y, x) order. */

@@ -237,6 +237,202 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
 }
 
 // ---------------------------------------------------------------------------
+// K1+K2 in one launch, for calls of a few frames where the chain of dependent
+// launches (ingest + one resize per level), not the arithmetic, sets the time.
+//
+// A workgroup owns one SLAMFE_PT_W x SLAMFE_PT_H tile of level 0 and the
+// corresponding piece of every level (host-made range tables, see
+// build_fused_pyramid_tables).  It reads its level-0 region from the input frame
+// (gray copy or BGR -> gray, as k_ingest), and then computes level after level
+// in LDS, each from the one before -- the same taps and the same fixed-point
+// arithmetic as k_resize: h = s[o] * (256 - c) + s[o + 1] * c per source row,
+// out = (h0 * (256 - w) + h1 * w + 2^15) >> 16 -- storing the columns and rows it
+// owns.  The region it has to compute is a little larger than what it owns (the
+// taps of the next level's region reach into the neighbours' pixels); that halo
+// is recomputed by both neighbours instead of being exchanged.
+// ---------------------------------------------------------------------------
+#define PF_THREADS 512
+#define PF_WAVES (PF_THREADS / 64)
+#define PF_ROWS 8 /* rows a thread fetches per batch of independent loads */
+
+// Four horizontally adjacent gray pixels of the input frame as one dword; `valid`
+// (1..4) of them exist.  Full groups are fetched with unaligned dword loads.
+__device__ __forceinline__ uint32_t pf_load4(const uint8_t* __restrict__ p, int channels, int valid)
+{
+    if (channels == 1) {
+        if (valid == 4) return load_u32_unaligned(p);
+        uint32_t v = 0;
+        for (int k = 0; k < valid; ++k) v |= (uint32_t)p[k] << (8 * k);
+        return v;
+    }
+    uint8_t q[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid == 4) {
+        const uint32_t a = load_u32_unaligned(p), b = load_u32_unaligned(p + 4), c = load_u32_unaligned(p + 8);
+        __builtin_memcpy(q, &a, 4);
+        __builtin_memcpy(q + 4, &b, 4);
+        __builtin_memcpy(q + 8, &c, 4);
+    } else {
+        for (int k = 0; k < 3 * valid; ++k) q[k] = p[k];
+    }
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        v |= (uint32_t)((q[3 * k] * SLAMFE_B2Y + q[3 * k + 1] * SLAMFE_G2Y + q[3 * k + 2] * SLAMFE_R2Y +
+                         (1 << (SLAMFE_GRAY_SHIFT - 1))) >> SLAMFE_GRAY_SHIFT) << (8 * k);
+    return v;
+}
+
+__global__ __launch_bounds__(PF_THREADS) void k_pyramid_fused(slamfe_dev_geom g, const uint8_t* __restrict__ in,
+                                                              int stride, size_t frame_stride, int channels,
+                                                              uint8_t* __restrict__ pyr,
+                                                              const uint32_t* __restrict__ taps)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t pl[];
+    uint32_t* rng = reinterpret_cast<uint32_t*>(pl);                 // [axis][level][need, own]
+    uint32_t* tapc = reinterpret_cast<uint32_t*>(pl + g.pt_off_taps); // per level: x taps, then y taps
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx = blockIdx.x, ty = blockIdx.y, f = blockIdx.z;
+    const int L = g.nlevels;
+    if (tid < 4 * L) {
+        const int axis = tid / (2 * L), rem = tid - axis * 2 * L;
+        const int l = rem >> 1, wsel = rem & 1;
+        rng[tid] = taps[(axis ? g.ptab_y : g.ptab_x) + (size_t)(l * (axis ? g.pt_y : g.pt_x) + (axis ? ty : tx)) * 2 + wsel];
+    }
+    __syncthreads();
+    auto need = [&](int axis, int l, int& a, int& b) {
+        const uint32_t v = rng[(axis * L + l) * 2];
+        a = (int)(v & 0xffffu);
+        b = (int)(v >> 16);
+    };
+    auto own = [&](int axis, int l, int& a, int& b) {
+        const uint32_t v = rng[(axis * L + l) * 2 + 1];
+        a = (int)(v & 0xffffu);
+        b = (int)(v >> 16);
+    };
+    // tap cache: the taps of every level's needed columns and rows, as one index
+    // space so that a thread's loads are independent of each other (and of the
+    // level-0 region loads below)
+    {
+        int tb[SLAMFE_MAX_LEVELS + 1]; // first cache entry of each level
+        tb[0] = tb[1] = 0;
+        for (int l = 1; l < L; ++l) {
+            int x0, x1, y0, y1;
+            need(0, l, x0, x1);
+            need(1, l, y0, y1);
+            tb[l + 1] = tb[l] + max(x1 - x0, 0) + max(y1 - y0, 0);
+        }
+        for (int e = tid; e < tb[L]; e += PF_THREADS) {
+            int l = 1;
+            while (l + 1 < L && e >= tb[l + 1]) ++l;
+            int x0, x1, y0, y1;
+            need(0, l, x0, x1);
+            need(1, l, y0, y1);
+            const int i = e - tb[l], nx = max(x1 - x0, 0);
+            tapc[e] = i < nx ? taps[g.lv[l].tap_x + x0 + i] : taps[g.lv[l].tap_y + y0 + (i - nx)];
+        }
+    }
+    uint8_t* bufA = pl + g.pt_off_a;
+    uint8_t* bufB = pl + g.pt_off_b;
+    // the owned part of a level's LDS region goes to the pyramid as dwords (owned
+    // columns start at a multiple of 4; rows are padded to 64 bytes)
+    // (items = groups of four columns, dealt to the threads as one index space:
+    // the pieces are far narrower than 64 lanes x 4 columns)
+    auto store_owned = [&](int l, const uint8_t* buf, int nx0, int ny0, int pitch) {
+        int ox0, ox1, oy0, oy1;
+        own(0, l, ox0, ox1);
+        own(1, l, oy0, oy1);
+        uint8_t* dst = pyr + (size_t)f * g.frame_bytes + g.lv[l].off;
+        const int dp = g.lv[l].pitch;
+        const int ng = (max(ox1 - ox0, 0) + 3) >> 2, items = ng * max(oy1 - oy0, 0);
+        const float inv = 1.0f / (float)max(ng, 1);
+        for (int i = tid; i < items; i += PF_THREADS) {
+            const int r = (int)(((float)i + 0.5f) * inv), y = oy0 + r, x = ox0 + 4 * (i - r * ng);
+            const uint8_t* sp = buf + (y - ny0) * pitch + (x - nx0);
+            const uint32_t v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+            *reinterpret_cast<uint32_t*>(dst + (size_t)y * dp + x) = v;
+        }
+    };
+    // ---- level 0: the needed region, four pixels per load, PF_ROWS rows per thread
+    // in flight together
+    int sx0, sx1, sy0, sy1;
+    need(0, 0, sx0, sx1);
+    need(1, 0, sy0, sy1);
+    int spitch = ((sx1 - sx0 + 3) & ~3) + 4;
+    {
+        const uint8_t* src = in ? in + (size_t)f * frame_stride : pyr + (size_t)f * g.frame_bytes + g.lv[0].off;
+        const int sstride = in ? stride : g.lv[0].pitch, ch = in ? channels : 1;
+        const int nxw = sx1 - sx0, nyh = sy1 - sy0, nd = (nxw + 3) >> 2;
+        for (int yb = 0; yb < nyh; yb += PF_WAVES * PF_ROWS)
+            for (int xb = 0; xb < nd; xb += 64) {
+                const int xd = xb + lane;
+                uint32_t v[PF_ROWS];
+#pragma unroll
+                for (int u = 0; u < PF_ROWS; ++u) {
+                    const int y = yb + wv + PF_WAVES * u;
+                    v[u] = 0;
+                    if (y < nyh && xd < nd)
+                        v[u] = pf_load4(src + (size_t)(sy0 + y) * sstride + (size_t)(sx0 + 4 * xd) * ch, ch,
+                                        min(4, nxw - 4 * xd));
+                }
+#pragma unroll
+                for (int u = 0; u < PF_ROWS; ++u) {
+                    const int y = yb + wv + PF_WAVES * u;
+                    if (y < nyh && xd < nd) *reinterpret_cast<uint32_t*>(bufA + y * spitch + 4 * xd) = v[u];
+                }
+            }
+    }
+    __syncthreads();
+    if (in) store_owned(0, bufA, sx0, sy0, spitch);
+    // ---- levels 1 .. L-1, ping-pong between the two buffers
+    const uint8_t* S = bufA;
+    uint8_t* D = bufB;
+    int tbase = 0;
+    for (int l = 1; l < L; ++l) {
+        int dx0, dx1, dy0, dy1;
+        need(0, l, dx0, dx1);
+        need(1, l, dy0, dy1);
+        const int nx = max(dx1 - dx0, 0), ny = max(dy1 - dy0, 0);
+        const int dpitch = ((nx + 3) & ~3) + 4;
+        const uint32_t* txs = tapc + tbase;
+        const uint32_t* tys = txs + nx;
+        const int ng = (nx + 3) >> 2, items = ng * ny;
+        const float inv = 1.0f / (float)max(ng, 1);
+        for (int i = tid; i < items; i += PF_THREADS) {
+            const int y = (int)(((float)i + 0.5f) * inv), x = 4 * (i - y * ng);
+            const uint32_t tyv = tys[y];
+            const int yo = (int)(tyv & 0xffffu) - sy0;
+            const uint32_t w1 = tyv >> 16, w0 = 256u - w1;
+            const uint8_t* r0 = S + yo * spitch;
+            const uint8_t* r1 = r0 + (w1 ? spitch : 0);
+            uint32_t outv = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (x + k < nx) {
+                    const uint32_t txv = txs[x + k];
+                    const int o = (int)(txv & 0xffffu) - sx0;
+                    const uint32_t c1 = txv >> 16, c0 = 256u - c1;
+                    const int o1 = o + (c1 ? 1 : 0);
+                    const uint32_t h0 = r0[o] * c0 + r0[o1] * c1;
+                    const uint32_t h1 = r1[o] * c0 + r1[o1] * c1;
+                    outv |= ((h0 * w0 + h1 * w1 + (1u << 15)) >> 16) << (8 * k);
+                }
+            }
+            *reinterpret_cast<uint32_t*>(D + y * dpitch + x) = outv;
+        }
+        __syncthreads();
+        store_owned(l, D, dx0, dy0, dpitch);
+        // the next level reads D and overwrites S, which nobody reads any more
+        const uint8_t* t = S;
+        S = D;
+        D = const_cast<uint8_t*>(t);
+        sx0 = dx0;
+        sy0 = dy0;
+        spitch = dpitch;
+        tbase += nx + ny;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3+K6  FAST-9/16 (segment test, score, strict 3x3 NMS, border filter) fused
 //        with the 7x7 sigma=2 blur of the same level.
 //        (detector->detect, Init.cc:76, per level inside cv::ORB; and the
@@ -643,6 +839,23 @@ int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, 
         LAUNCH_CHECK();
     }
     return 0;
+}
+
+int slamfe_launch_pyramid_fused(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* d_in,
+                                int stride, size_t frame_stride, int channels, uint8_t* pyr,
+                                const uint32_t* taps)
+{
+    if (g.pt_x <= 0 || nframes <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pyramid_fused, dim3((unsigned)g.pt_x, (unsigned)g.pt_y, (unsigned)nframes), dim3(PF_THREADS),
+                       g.pt_lds, s, g, d_in, stride, frame_stride, channels, pyr, taps);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_image_init(void)
+{
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid_fused),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SLAMFE_PT_LDS_MAX);
 }
 
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,

@@ -750,9 +750,11 @@ int slamfe_projection_init(void)
 // Raise the dynamic-LDS limits of the two kernels that may need more than the
 // default 64 KiB.
 int slamfe_select_init(size_t sort_lds_bytes);
+int slamfe_image_init(void);
 int slamfe_kernels_init(size_t sort_lds_bytes)
 {
     int e = slamfe_select_init(sort_lds_bytes);
     if (e) return e;
+    if ((e = slamfe_image_init())) return e;
     return slamfe_projection_init();
 }

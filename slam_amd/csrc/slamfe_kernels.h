@@ -17,6 +17,11 @@ int slamfe_launch_ingest_scaled(hipStream_t s, const uint8_t* d_in, int stride, 
                                 uint8_t* bgr_out, int bpitch);
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
                           const uint32_t* taps);
+/* Ingest + all pyramid levels in one launch (a few frames per call); d_in = NULL:
+ * level 0 is already in pyr.  Needs g.pt_x > 0. */
+int slamfe_launch_pyramid_fused(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* d_in,
+                                int stride, size_t frame_stride, int channels, uint8_t* pyr,
+                                const uint32_t* taps);
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
                             uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt);
 int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,

@@ -15,21 +15,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from slam_amd import abi, synth  # noqa: E402
 from slam_amd.frontend import FrontEnd  # noqa: E402
-
-
-def window_tests(xy, uv, radius, max_w, max_h):
-    """Gate tests of the grid query: points in the 3x3 cells around each keypoint."""
-    cell = max(radius * 1.0001 + 1e-3, max(max_w, max_h) / 128.0)
-    gx = int(min(128, np.floor(max_w / cell) + 1))
-    gy = int(min(128, np.floor(max_h / cell) + 1))
-    cx = np.clip(np.floor(uv[:, 0].astype(np.float64) / cell), 0, gx - 1).astype(np.int64)
-    cy = np.clip(np.floor(uv[:, 1].astype(np.float64) / cell), 0, gy - 1).astype(np.int64)
-    cnt = np.zeros((gy + 2, gx + 2), np.int64)
-    np.add.at(cnt, (cy + 1, cx + 1), 1)
-    win = sum(cnt[1 + dy:gy + 1 + dy, 1 + dx:gx + 1 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1))
-    kx = np.clip(np.floor(xy[:, 0].astype(np.float64) / cell), 0, gx - 1).astype(np.int64)
-    ky = np.clip(np.floor(xy[:, 1].astype(np.float64) / cell), 0, gy - 1).astype(np.int64)
-    return int(win[ky, kx].sum())
+from bench import window_gate_tests as window_tests  # noqa: E402
 
 
 def case(npts, ninl_cap, reps):
