@@ -464,6 +464,13 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
                                      c->level_kept, c->level_cutoff, slot_base, c->nslots, c->kp_key,
                                      c->kp_level, c->kp_count, c->max_kp, c->sort_lds));
     }
+    if (few) {
+        ProbeScope ps(c, SLAMFE_STAGE_DESCRIBE);
+        KCHK(c, slamfe_launch_orient_describe(s, g, n, c->pyr, c->blur, slot_base, c->nslots, c->kp_key,
+                                              c->kp_level, c->kp_count, c->kp_mom, c->kps, c->kp_rot, c->desc,
+                                              c->max_kp, c->p.mode, c->p.patch_size));
+        return SLAMFE_OK;
+    }
     {
         ProbeScope ps(c, SLAMFE_STAGE_ORIENT);
         KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
@@ -542,6 +549,41 @@ int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kp
         size_t n = (size_t)ncopy[(size_t)i];
         if (n && kps) memcpy(kps + (size_t)i * cap, hk + (size_t)i * K, n * sizeof(slamfe_keypoint));
         if (n && desc) memcpy(desc + (size_t)i * cap * 32, hd + (size_t)i * K * 32, n * 32);
+    }
+    return worst;
+}
+
+// The results of the nf frames just extracted (consecutive slots of the ring) for
+// a call of a few frames: one kernel writes counts and rows into the pinned
+// staging arrays, one wait, then the copies into the caller's arrays.
+int export_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kps, uint8_t* desc, int cap,
+                  int* n_out)
+{
+    int rc = ensure_host_staging(c);
+    if (rc) return rc;
+    const size_t K = (size_t)c->max_kp;
+    uint8_t* hk = c->h_out;
+    uint8_t* hd = c->h_out + (size_t)c->p.max_batch * K * sizeof(slamfe_keypoint);
+    KCHK(c, slamfe_launch_export(c->stream, c->kp_count, c->kps, c->desc, slots[0], c->nslots, c->max_kp, nf,
+                                 (kps || desc) ? 1 : 0, c->h_cnt, hk, hd));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int worst = SLAMFE_OK;
+    for (int i = 0; i < nf; ++i) {
+        const int n = c->h_cnt[i];
+        c->slot_count_host[(size_t)slots[i]] = n;
+        if (n_out) n_out[i] = n;
+        if (n > c->max_kp) {
+            worst = fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the context's max_keypoints %d", n,
+                         c->max_kp);
+            continue;
+        }
+        if ((kps || desc) && n > cap) {
+            worst = fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the caller's capacity %d", n, cap);
+            continue;
+        }
+        if (n && kps)
+            memcpy(kps + (size_t)i * cap, hk + (size_t)i * K * sizeof(slamfe_keypoint), (size_t)n * sizeof(slamfe_keypoint));
+        if (n && desc) memcpy(desc + (size_t)i * cap * 32, hd + (size_t)i * K * 32, (size_t)n * 32);
     }
     return worst;
 }
@@ -762,6 +804,7 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
         if (frame_handles) frame_handles[i] = hd[(size_t)i];
         slots[(size_t)i] = slot_of(c, hd[(size_t)i]);
     }
+    if (n < SLAMFE_FEW_FRAMES && c->max_kp % 4 == 0) return export_frames(c, slots.data(), n, kps, desc, cap, n_out);
     return download_frames(c, slots.data(), n, kps, desc, cap, n_out);
 }
 

@@ -19,6 +19,68 @@ __device__ __constant__ int8_t c_pattern[1024] = SLAMFE_PATTERN_INIT;
 //   T += dot4(x, inside ? u + 32 : 0)   S += dot4(x, inside ? 1 : 0)
 //   V += dot4(x, inside ? v + 16 : 0)   m10 = T - 32 S,  m01 = V - 16 S
 // leaving three dot products per loaded dword for every keypoint.
+// Per-lane constants of the moment sums: a lane owns one 16-byte half of one of
+// the 31 patch rows (62 lanes): one 16-byte load per keypoint.  (With four dword
+// loads per lane the address unit was the busiest part of the CU.)
+struct orient_lane {
+    uint32_t wT[4], wV[4], wS[4];
+    int trow, tcol;
+};
+
+__device__ __forceinline__ orient_lane orient_setup(int lane)
+{
+    // half-widths of the disc rows |v| = 0..15, one nibble each
+    const unsigned long long umax = 0x3689abcddeeeffffULL;
+    orient_lane W;
+    const int row = lane >> 1, half = lane & 1;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int dw = 4 * half + it;
+        const int v = row - 15, av = v < 0 ? -v : v;
+        const int d = row < 31 ? (int)((umax >> (4 * av)) & 15ULL) : -1;
+        uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * dw + k - 15;
+            if (u >= -d && u <= d) {
+                a |= (uint32_t)(u + 32) << (8 * k);
+                b |= (uint32_t)(v + 16) << (8 * k);
+                c |= 1u << (8 * k);
+            }
+        }
+        W.wT[it] = a;
+        W.wV[it] = b;
+        W.wS[it] = c;
+    }
+    W.trow = row < 31 ? row : 0;
+    W.tcol = 16 * half;
+    return W;
+}
+
+// The lane's 16 bytes of the patch whose top-left corner is `base` (= centre - 15, - 15).
+__device__ __forceinline__ uint4 orient_load(const orient_lane& W, const uint8_t* __restrict__ base, int pitch,
+                                             int lane)
+{
+    uint4 x4 = make_uint4(0, 0, 0, 0);
+    if (lane < 62) __builtin_memcpy(&x4, base + W.trow * pitch + W.tcol, 16);
+    return x4;
+}
+
+// m10, m01 of the disc from the lanes' 16-byte pieces (in every lane).
+__device__ __forceinline__ void orient_moments(const orient_lane& W, const uint4& x4, int& m10, int& m01)
+{
+    const uint32_t xs[4] = {x4.x, x4.y, x4.z, x4.w};
+    uint32_t T = 0, V = 0, S = 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        T = __builtin_amdgcn_udot4(xs[it], W.wT[it], T, false);
+        V = __builtin_amdgcn_udot4(xs[it], W.wV[it], V, false);
+        S = __builtin_amdgcn_udot4(xs[it], W.wS[it], S, false);
+    }
+    m10 = wave_sum((int)T - 32 * (int)S);
+    m01 = wave_sum((int)V - 16 * (int)S);
+}
+
 __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
                                                 int slot_base, int nslots,
                                                 const uint32_t* __restrict__ kp_key,
@@ -37,33 +99,7 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
     if (wave >= n) return;
-    // half-widths of the disc rows |v| = 0..15, one nibble each
-    const unsigned long long umax = 0x3689abcddeeeffffULL;
-    // A lane owns one 16-byte half of one of the 31 patch rows (62 lanes): one
-    // 16-byte load per keypoint.  (With four dword loads per lane the address unit
-    // was the busiest part of the CU.)
-    uint32_t wT[4], wV[4], wS[4];
-    const int row = lane >> 1, half = lane & 1;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int dw = 4 * half + it;
-        const int v = row - 15, av = v < 0 ? -v : v;
-        const int d = row < 31 ? (int)((umax >> (4 * av)) & 15ULL) : -1;
-        uint32_t a = 0, b = 0, c = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int u = 4 * dw + k - 15;
-            if (u >= -d && u <= d) {
-                a |= (uint32_t)(u + 32) << (8 * k);
-                b |= (uint32_t)(v + 16) << (8 * k);
-                c |= 1u << (8 * k);
-            }
-        }
-        wT[it] = a;
-        wV[it] = b;
-        wS[it] = c;
-    }
-    const int trow = row < 31 ? row : 0, tcol = 16 * half;
+    const orient_lane W = orient_setup(lane);
     const uint8_t* frame = pyr + (size_t)f * g.frame_bytes;
     const uint32_t* keys = kp_key + (size_t)slot * max_kp;
     const uint32_t* levels = kp_level + (size_t)slot * max_kp;
@@ -80,20 +116,38 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
         const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
         if (cx < 16 || cy < 16 || cx >= w - 17 || cy >= h - 16) continue; // reads must stay inside
         const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 15) * pitch + (cx - 15);
-        uint32_t T = 0, V = 0, S = 0;
-        uint4 x4 = make_uint4(0, 0, 0, 0);
-        if (lane < 62) __builtin_memcpy(&x4, base + trow * pitch + tcol, 16);
-        const uint32_t xs[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            T = __builtin_amdgcn_udot4(xs[it], wT[it], T, false);
-            V = __builtin_amdgcn_udot4(xs[it], wV[it], V, false);
-            S = __builtin_amdgcn_udot4(xs[it], wS[it], S, false);
-        }
-        const int m10 = wave_sum((int)T - 32 * (int)S);
-        const int m01 = wave_sum((int)V - 16 * (int)S);
+        const uint4 x4 = orient_load(W, base, pitch, lane);
+        int m10, m01;
+        orient_moments(W, x4, m10, m01);
         if (lane == 0) kp_mom[(size_t)slot * max_kp + idx] = make_int2(m10, m01);
     }
+}
+
+// The cv::KeyPoint record of a selected keypoint and cos / sin of its angle.
+__device__ __forceinline__ slamfe_keypoint finish_record(uint32_t key, int l, float scale, int2 m, int mode,
+                                                         int patch_size, float2* rot)
+{
+    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+    slamfe_keypoint k;
+    if (mode == SLAMFE_MODE_ORB) {
+        k.angle = slamfe_fast_atan2((float)m.y, (float)m.x);
+        k.x = (float)cx * scale;
+        k.y = (float)cy * scale;
+        k.size = (float)patch_size * scale;
+        k.octave = l;
+    } else {
+        k.angle = -1.f;
+        k.x = (float)cx;
+        k.y = (float)cy;
+        k.size = 7.f;
+        k.octave = 0;
+    }
+    k.response = (float)SLAMFE_KEY_S(key);
+    k.class_id = -1;
+    float sn, cs;
+    slamfe_sincos_deg(k.angle, &sn, &cs);
+    *rot = make_float2(cs, sn);
+    return k;
 }
 
 __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base, int nslots,
@@ -116,29 +170,10 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
     const uint32_t key = kp_key[e];
     int l = (int)kp_level[e];
     if (l < 0 || l >= g.nlevels) l = 0;
-    const float scale = g.lv[l].scale;
-    const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
-    slamfe_keypoint k;
-    if (mode == SLAMFE_MODE_ORB) {
-        int2 m = kp_mom[e];
-        k.angle = slamfe_fast_atan2((float)m.y, (float)m.x);
-        k.x = (float)cx * scale;
-        k.y = (float)cy * scale;
-        k.size = (float)patch_size * scale;
-        k.octave = l;
-    } else {
-        k.angle = -1.f;
-        k.x = (float)cx;
-        k.y = (float)cy;
-        k.size = 7.f;
-        k.octave = 0;
-    }
-    k.response = (float)SLAMFE_KEY_S(key);
-    k.class_id = -1;
-    kps[e] = k;
-    float sn, cs;
-    slamfe_sincos_deg(k.angle, &sn, &cs);
-    kp_rot[e] = make_float2(cs, sn);
+    float2 rot;
+    const int2 m = mode == SLAMFE_MODE_ORB ? kp_mom[e] : make_int2(0, 0);
+    kps[e] = finish_record(key, l, g.lv[l].scale, m, mode, patch_size, &rot);
+    kp_rot[e] = rot;
 }
 
 // ---------------------------------------------------------------------------
@@ -160,6 +195,86 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
 // bits are identical.  Rounding to the nearest integer (ties to even, as
 // cvRound) is the addition of 1.5 * 2^23, which leaves the integer in the low
 // mantissa bits.
+typedef float desc_v2f __attribute__((ext_vector_type(2)));
+#define DP_NIT ((DP_ROWS * DP_PC + 63) / 64)
+
+struct describe_lane {
+    desc_v2f P[4][2], Q[4][2];
+    int trow[DP_NIT], tcol[DP_NIT];
+};
+
+__device__ __forceinline__ describe_lane describe_setup(int lane)
+{
+    describe_lane D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int8_t* t = c_pattern + (j * 64 + lane) * 4;
+        D.P[j][0] = (desc_v2f){(float)t[0], (float)t[0]};
+        D.Q[j][0] = (desc_v2f){(float)t[1], (float)t[1]};
+        D.P[j][1] = (desc_v2f){(float)t[2], (float)t[2]};
+        D.Q[j][1] = (desc_v2f){(float)t[3], (float)t[3]};
+    }
+    // The patch is fetched in 16-byte pieces (unaligned in memory): the kernel's
+    // time is the address unit's, which spends about as long on a wave's dword
+    // loads as on its 16-byte loads.
+#pragma unroll
+    for (int it = 0; it < DP_NIT; ++it) {
+        const int t = it * 64 + lane, row = t / DP_PC;
+        D.trow[it] = row < DP_ROWS ? row : 0;
+        D.tcol[it] = 16 * (t - row * DP_PC);
+    }
+    return D;
+}
+
+// The lane's pieces of the patch whose top-left corner is `base` (= centre - 18, - 18).
+// (The last piece of a row reaches 8 bytes past the 40 that are used: into the
+// row's padding or the next row, always inside the pyramid buffer.)
+__device__ __forceinline__ void describe_load(const describe_lane& D, const uint8_t* __restrict__ base, int pitch,
+                                              int lane, uint4 (&r)[DP_NIT])
+{
+#pragma unroll
+    for (int it = 0; it < DP_NIT; ++it) {
+        r[it] = make_uint4(0, 0, 0, 0);
+        if (it < DP_NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC)
+            __builtin_memcpy(&r[it], base + D.trow[it] * pitch + D.tcol[it], 16);
+    }
+}
+
+// Stage the pieces in the wave's LDS slice, rotate the pattern by (cos, sin) = rot,
+// compare the 256 sample pairs; lanes 0..3 store the 32 descriptor bytes.
+__device__ __forceinline__ void describe_finish(const describe_lane& D, const uint4 (&r)[DP_NIT], uint4* my,
+                                                float2 rot, int lane, uint8_t* __restrict__ out32)
+{
+#pragma unroll
+    for (int it = 0; it < DP_NIT; ++it)
+        if (it < DP_NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC) my[it * 64 + lane] = r[it];
+    // only this wavefront reads what it wrote: LDS operations of one wave are
+    // ordered, the fences keep the compiler from moving accesses across
+    wave_lds_fence();
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * DP_PITCH + 18;
+    const desc_v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
+    const desc_v2f magic = {12582912.f, 12582912.f};
+    unsigned long long word[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            desc_v2f pt = D.P[j][e] * AB + D.Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
+            pt = pt + magic;
+            const int ix = (short)__float_as_int(pt.x), iy = (short)__float_as_int(pt.y);
+            v[e] = c[iy * DP_PITCH + ix];
+        }
+        word[j] = __ballot(v[0] < v[1]);
+    }
+    if (lane < 4) {
+        unsigned long long o = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+        reinterpret_cast<unsigned long long*>(out32)[lane] = o;
+    }
+    // the next keypoint's staging must not overtake these LDS reads
+    wave_lds_fence();
+}
+
 __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8_t* __restrict__ blur,
                                                   int slot_base, int nslots,
                                                   const uint32_t* __restrict__ kp_key,
@@ -168,7 +283,6 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   const float2* __restrict__ kp_rot,
                                                   uint8_t* __restrict__ desc, int max_kp, int nframes)
 {
-    typedef float v2f __attribute__((ext_vector_type(2)));
     __shared__ uint4 patch128[4][DP_ROWS * DP_PC];
     const int f = wg_frame();
     if (f >= nframes) return;
@@ -180,28 +294,8 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
     int n = kp_count[slot];
     if (n > max_kp) n = max_kp;
     if (wave >= n) return;
-    v2f P[4][2], Q[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int8_t* t = c_pattern + (j * 64 + lane) * 4;
-        P[j][0] = (v2f){(float)t[0], (float)t[0]};
-        Q[j][0] = (v2f){(float)t[1], (float)t[1]};
-        P[j][1] = (v2f){(float)t[2], (float)t[2]};
-        Q[j][1] = (v2f){(float)t[3], (float)t[3]};
-    }
-    // The patch is fetched in 16-byte pieces (unaligned in memory): the kernel's
-    // time is the address unit's, which spends about as long on a wave's dword
-    // loads as on its 16-byte loads.
-    constexpr int NIT = (DP_ROWS * DP_PC + 63) / 64;
-    int trow[NIT], tcol[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int t = it * 64 + lane, row = t / DP_PC;
-        trow[it] = row < DP_ROWS ? row : 0;
-        tcol[it] = 16 * (t - row * DP_PC);
-    }
+    const describe_lane D = describe_setup(lane);
     uint4* my = patch128[wv];
-    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * DP_PITCH + 18;
     const uint8_t* frame = blur + (size_t)f * g.frame_bytes;
     const uint32_t* keys = kp_key + (size_t)slot * max_kp;
     const uint32_t* levels = kp_level + (size_t)slot * max_kp;
@@ -222,47 +316,118 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
         const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
         if (cx < 18 || cy < 18 || cx >= w - 22 || cy >= h - 18) continue; // reads must stay inside
         const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 18) * pitch + (cx - 18);
-        // (the last piece of a row reaches 8 bytes past the 40 that are used:
-        // into the row's padding or the next row, always inside the pyramid buffer)
-        uint4 r[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            r[it] = make_uint4(0, 0, 0, 0);
-            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC)
-                __builtin_memcpy(&r[it], base + trow[it] * pitch + tcol[it], 16);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-            if (it < NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC) my[it * 64 + lane] = r[it];
-        // only this wavefront reads what it wrote: LDS operations of one wave are
-        // ordered, the fences keep the compiler from moving accesses across
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
-        const v2f magic = {12582912.f, 12582912.f};
-        unsigned long long word[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int v[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                v2f pt = P[j][e] * AB + Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
-                pt = pt + magic;
-                const int ix = (short)__float_as_int(pt.x), iy = (short)__float_as_int(pt.y);
-                v[e] = c[iy * DP_PITCH + ix];
-            }
-            word[j] = __ballot(v[0] < v[1]);
-        }
-        if (lane < 4) {
-            unsigned long long o = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
-            reinterpret_cast<unsigned long long*>(desc + ((size_t)slot * max_kp + idx) * 32)[lane] = o;
-        }
-        // the next keypoint's staging must not overtake these LDS reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint4 r[DP_NIT];
+        describe_load(D, base, pitch, lane, r);
+        describe_finish(D, r, my, rot, lane, desc + ((size_t)slot * max_kp + idx) * 32);
     }
+}
+
+// Orientation, keypoint record and descriptor of a keypoint in one pass, for
+// calls of a few frames (one launch instead of three; every lane of the wave
+// evaluates the keypoint's angle and its cos / sin, which a batch leaves to one
+// lane per keypoint in k_finish).  The patch loads of both images are issued
+// together.  Same device functions, same results as k_orient + k_finish +
+// k_describe.
+__global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
+                                                         const uint8_t* __restrict__ blur, int slot_base,
+                                                         int nslots, const uint32_t* __restrict__ kp_key,
+                                                         const uint32_t* __restrict__ kp_level,
+                                                         const int32_t* __restrict__ kp_count,
+                                                         int2* __restrict__ kp_mom,
+                                                         slamfe_keypoint* __restrict__ kps,
+                                                         float2* __restrict__ kp_rot, uint8_t* __restrict__ desc,
+                                                         int max_kp, int mode, int patch_size, int nframes)
+{
+    __shared__ uint4 patch128[4][DP_ROWS * DP_PC];
+    const int f = wg_frame();
+    if (f >= nframes) return;
+    const int slot = (slot_base + f) % nslots;
+    const int wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(wg_item() * 4 + wv);
+    const int nwaves = (int)gridDim.y * 4;
+    int n = kp_count[slot];
+    if (n > max_kp) n = max_kp;
+    if (wave >= n) return;
+    const orient_lane W = orient_setup(lane);
+    const describe_lane D = describe_setup(lane);
+    uint4* my = patch128[wv];
+    const uint32_t* keys = kp_key + (size_t)slot * max_kp;
+    const uint32_t* levels = kp_level + (size_t)slot * max_kp;
+    uint32_t next_key = keys[wave], next_level = levels[wave];
+    for (int idx = wave; idx < n; idx += nwaves) { // uniform per wave
+        const uint32_t key = next_key;
+        int l = (int)next_level;
+        if (idx + nwaves < n) { // fetched while this keypoint is processed
+            next_key = keys[idx + nwaves];
+            next_level = levels[idx + nwaves];
+        }
+        if (l < 0 || l >= g.nlevels) l = 0; // never true for entries written by k_select_write
+        const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
+        const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
+        const size_t e = (size_t)slot * max_kp + idx;
+        const size_t lvl = (size_t)f * g.frame_bytes + g.lv[l].off;
+        // (the guards are those of k_orient and k_describe: reads must stay inside)
+        const bool can_orient = mode == SLAMFE_MODE_ORB && !(cx < 16 || cy < 16 || cx >= w - 17 || cy >= h - 16);
+        const bool can_describe = !(cx < 18 || cy < 18 || cx >= w - 22 || cy >= h - 18);
+        uint4 x4 = make_uint4(0, 0, 0, 0);
+        uint4 r[DP_NIT];
+        if (can_orient) x4 = orient_load(W, pyr + lvl + (size_t)(cy - 15) * pitch + (cx - 15), pitch, lane);
+        if (can_describe) describe_load(D, blur + lvl + (size_t)(cy - 18) * pitch + (cx - 18), pitch, lane, r);
+        int2 m = make_int2(0, 0);
+        if (can_orient) {
+            orient_moments(W, x4, m.x, m.y);
+            if (lane == 0) kp_mom[e] = m;
+        }
+        float2 rot;
+        const slamfe_keypoint k = finish_record(key, l, g.lv[l].scale, m, mode, patch_size, &rot);
+        if (lane == 0) {
+            kps[e] = k;
+            kp_rot[e] = rot;
+        }
+        if (can_describe) describe_finish(D, r, my, rot, lane, desc + e * 32);
+    }
+}
+
+// Results of a few frames straight into pinned host memory: the keypoint count
+// of every frame, its cv::KeyPoint records and descriptor rows (16 bytes per
+// lane).  One launch and one stream synchronisation replace the read-back of
+// the counts, a second round trip for the rows and three transfer launches.
+// Workgroup (chunk, frame) moves rows [256 * chunk, 256 * chunk + 256) of the frame.
+__global__ __launch_bounds__(256) void k_export(const int32_t* __restrict__ kp_count,
+                                                const slamfe_keypoint* __restrict__ kps,
+                                                const uint8_t* __restrict__ desc, int slot_base, int nslots,
+                                                int max_kp, int with_rows, int32_t* __restrict__ h_cnt,
+                                                uint8_t* __restrict__ h_kps, uint8_t* __restrict__ h_desc)
+{
+    const int f = blockIdx.y, slot = (slot_base + f) % nslots;
+    const int count = kp_count[slot];
+    if (blockIdx.x == 0 && threadIdx.x == 0) h_cnt[f] = count;
+    if (!with_rows) return;
+    const int n = min(count, max_kp), r0 = (int)blockIdx.x * 256;
+    if (r0 >= n) return;
+    const int rows = min(256, n - r0);
+    const size_t K = (size_t)max_kp;
+    // (slots and the host arrays hold max_kp rows per frame, so the last 16-byte
+    // piece may cover bytes past the frame's rows but never past its array)
+    const uint4* sk = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(kps) +
+                                                     ((size_t)slot * K + r0) * sizeof(slamfe_keypoint));
+    uint4* dk = reinterpret_cast<uint4*>(h_kps + ((size_t)f * K + r0) * sizeof(slamfe_keypoint));
+    const int nk = (rows * (int)sizeof(slamfe_keypoint) + 15) / 16;
+    for (int i = threadIdx.x; i < nk; i += 256) dk[i] = sk[i];
+    const uint4* sd = reinterpret_cast<const uint4*>(desc + ((size_t)slot * K + r0) * 32);
+    uint4* dd = reinterpret_cast<uint4*>(h_desc + ((size_t)f * K + r0) * 32);
+    for (int i = threadIdx.x; i < rows * 2; i += 256) dd[i] = sd[i];
+}
+
+int slamfe_launch_export(hipStream_t s, const int32_t* kp_count, const slamfe_keypoint* kps, const uint8_t* desc,
+                         int slot_base, int nslots, int max_kp, int nframes, int with_rows, int32_t* h_cnt,
+                         uint8_t* h_kps, uint8_t* h_desc)
+{
+    hipLaunchKernelGGL(k_export, dim3(with_rows ? (max_kp + 255) / 256 : 1, nframes), dim3(256), 0, s, kp_count,
+                       kps, desc, slot_base, nslots, max_kp, with_rows, h_cnt, h_kps, h_desc);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
@@ -285,6 +450,23 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                        slot_base, nslots, kp_key, kp_level, kp_count,
                        reinterpret_cast<const int2*>(kp_mom), kps, reinterpret_cast<float2*>(kp_rot),
                        max_kp, mode, patch_size, nframes);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                                  const uint8_t* blur, int slot_base, int nslots, const uint32_t* kp_key,
+                                  const uint32_t* kp_level, const int32_t* kp_count, int32_t* kp_mom,
+                                  slamfe_keypoint* kps, float* kp_rot, uint8_t* desc, int max_kp, int mode,
+                                  int patch_size)
+{
+    long long est = 0;
+    for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
+    if (est < 64 || est > max_kp) est = max_kp;
+    // two keypoints per wavefront: a call of a few frames is short of waves, not of work
+    hipLaunchKernelGGL(k_orient_describe, frame_grid((int)((est + 7) / 8), nframes), dim3(256), 0, s, g, pyr,
+                       blur, slot_base, nslots, kp_key, kp_level, kp_count, reinterpret_cast<int2*>(kp_mom), kps,
+                       reinterpret_cast<float2*>(kp_rot), desc, max_kp, mode, patch_size, nframes);
     LAUNCH_CHECK();
     return 0;
 }

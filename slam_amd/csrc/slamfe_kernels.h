@@ -38,6 +38,19 @@ int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes,
                            const uint32_t* kp_level, const int32_t* kp_count, const float* kp_rot,
                            uint8_t* desc, int max_kp);
 
+/* k_orient + k_finish + k_describe as one launch (a few frames per call). */
+int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
+                                  const uint8_t* blur, int slot_base, int nslots, const uint32_t* kp_key,
+                                  const uint32_t* kp_level, const int32_t* kp_count, int32_t* kp_mom,
+                                  slamfe_keypoint* kps, float* kp_rot, uint8_t* desc, int max_kp, int mode,
+                                  int patch_size);
+
+/* Counts and (with_rows) keypoint records + descriptor rows of nframes consecutive
+ * slots into host-pinned arrays laid out [frame][max_kp]. */
+int slamfe_launch_export(hipStream_t s, const int32_t* kp_count, const slamfe_keypoint* kps, const uint8_t* desc,
+                         int slot_base, int nslots, int max_kp, int nframes, int with_rows, int32_t* h_cnt,
+                         uint8_t* h_kps, uint8_t* h_desc);
+
 /* Choose queries per lane and the train chunking for a match of at most
  * nq_max x nt_max rows (npairs independent pairs in one launch); the partial
  * buffer needs npairs * nchunks * cap * 8 bytes. */
