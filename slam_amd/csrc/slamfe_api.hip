@@ -20,7 +20,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -140,6 +142,34 @@ int fail(slamfe_ctx* c, int code, const char* fmt, ...)
             return fail((c), SLAMFE_E_DEVICE, "%s failed: %s", #call,                       \
                         hipGetErrorString((hipError_t)e_));                                 \
     } while (0)
+
+// Host-side phase times of a call, printed to stderr when the environment
+// variable SLAMFE_TRACE is set (a tuning aid; no effect otherwise).
+struct PhaseTrace {
+    bool on;
+    const char* what;
+    std::chrono::steady_clock::time_point t0, last;
+    std::string line;
+    explicit PhaseTrace(const char* name) : on(getenv("SLAMFE_TRACE") != nullptr), what(name)
+    {
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char* phase)
+    {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof buf, " %s %.1f", phase, std::chrono::duration<double, std::micro>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~PhaseTrace()
+    {
+        if (on)
+            fprintf(stderr, "[slamfe %s]%s | total %.1f us\n", what, line.c_str(),
+                    std::chrono::duration<double, std::micro>(last - t0).count());
+    }
+};
 
 // Events around `stage` while the probe is set on it (at most 64 intervals are kept).
 struct ProbeScope {
@@ -766,6 +796,7 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
                          uint64_t* frame_handles)
 {
     if (!c || !imgs) return SLAMFE_E_INVALID;
+    PhaseTrace tr("extract_batch");
     HIPCHK(c, hipSetDevice(c->p.device_id));
     if (n < 1 || n > c->p.max_batch)
         return fail(c, SLAMFE_E_INVALID, "batch of %d frames; context allows 1..%d", n,
@@ -779,6 +810,7 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
     if (rc) return rc;
     // the staging buffers may still feed the previous call's queued copies
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    tr.mark("setup");
     for (int i = 0; i < n; ++i)
         if (!imgs[i]) return fail(c, SLAMFE_E_INVALID, "imgs[%d] is NULL", i);
     // frames go to the pinned buffer in groups of about 2 MiB; each group's
@@ -796,16 +828,20 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
         HIPCHK(c, hipMemcpyAsync(c->in_stage + (size_t)i0 * fbytes, c->h_in + (size_t)i0 * fbytes,
                                  (size_t)(i1 - i0) * fbytes, hipMemcpyHostToDevice, c->stream));
     }
+    tr.mark("stage+h2d");
     std::vector<uint64_t> hd((size_t)n);
     rc = run_extract(c, c->in_stage, n, w, h, (int)row, fbytes, channels, hd.data());
     if (rc) return rc;
+    tr.mark("launches");
     std::vector<int> slots((size_t)n);
     for (int i = 0; i < n; ++i) {
         if (frame_handles) frame_handles[i] = hd[(size_t)i];
         slots[(size_t)i] = slot_of(c, hd[(size_t)i]);
     }
-    if (n < SLAMFE_FEW_FRAMES && c->max_kp % 4 == 0) return export_frames(c, slots.data(), n, kps, desc, cap, n_out);
-    return download_frames(c, slots.data(), n, kps, desc, cap, n_out);
+    rc = (n < SLAMFE_FEW_FRAMES && c->max_kp % 4 == 0) ? export_frames(c, slots.data(), n, kps, desc, cap, n_out)
+                                                      : download_frames(c, slots.data(), n, kps, desc, cap, n_out);
+    tr.mark("results");
+    return rc;
 }
 
 int slamfe_extract(slamfe_ctx* c, const uint8_t* img, int w, int h, int stride, int channels,

@@ -47,8 +47,12 @@ typedef struct slamfe_dev_geom {
     slamfe_dev_level lv[SLAMFE_MAX_LEVELS];
 } slamfe_dev_geom;
 
+#ifndef SLAMFE_PT_W
 #define SLAMFE_PT_W 128
+#endif
+#ifndef SLAMFE_PT_H
 #define SLAMFE_PT_H 32
+#endif
 #define SLAMFE_PT_LDS_MAX (96 * 1024)
 
 /* Candidate / keypoint key: y in bits 31..20, x in bits 19..8, score in 7..0,

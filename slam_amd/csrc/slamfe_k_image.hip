@@ -251,6 +251,25 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
 // taps of the next level's region reach into the neighbours' pixels); that halo
 // is recomputed by both neighbours instead of being exchanged.
 // ---------------------------------------------------------------------------
+#ifdef SLAMFE_STAMPS
+// Diagnostic build only: shader-clock and wall-clock stamps of workgroup (0,0,0)
+// at the phases of k_pyramid_fused, read back with slamfe_debug_stamps().
+__device__ unsigned long long g_pf_stamps[64];
+#define PF_STAMP(i)                                                                       \
+    do {                                                                                  \
+        if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0) {  \
+            g_pf_stamps[2 * (i)] = __builtin_amdgcn_s_memtime();                          \
+            g_pf_stamps[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                  \
+        }                                                                                 \
+    } while (0)
+extern "C" int slamfe_debug_stamps(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pf_stamps), (size_t)n * 8);
+}
+#else
+#define PF_STAMP(i)
+#endif
+
 #define PF_THREADS 512
 #define PF_WAVES (PF_THREADS / 64)
 #define PF_ROWS 8 /* rows a thread fetches per batch of independent loads */
@@ -293,12 +312,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyramid_fused(slamfe_dev_geom g,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = blockIdx.x, ty = blockIdx.y, f = blockIdx.z;
     const int L = g.nlevels;
+    PF_STAMP(0);
     if (tid < 4 * L) {
         const int axis = tid / (2 * L), rem = tid - axis * 2 * L;
         const int l = rem >> 1, wsel = rem & 1;
         rng[tid] = taps[(axis ? g.ptab_y : g.ptab_x) + (size_t)(l * (axis ? g.pt_y : g.pt_x) + (axis ? ty : tx)) * 2 + wsel];
     }
     __syncthreads();
+    PF_STAMP(1);
     auto need = [&](int axis, int l, int& a, int& b) {
         const uint32_t v = rng[(axis * L + l) * 2];
         a = (int)(v & 0xffffu);
@@ -382,7 +403,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyramid_fused(slamfe_dev_geom g,
             }
     }
     __syncthreads();
+    PF_STAMP(2);
     if (in) store_owned(0, bufA, sx0, sy0, spitch);
+    PF_STAMP(3);
     // ---- levels 1 .. L-1, ping-pong between the two buffers
     const uint8_t* S = bufA;
     uint8_t* D = bufB;
@@ -420,7 +443,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyramid_fused(slamfe_dev_geom g,
             *reinterpret_cast<uint32_t*>(D + y * dpitch + x) = outv;
         }
         __syncthreads();
+        PF_STAMP(2 + 2 * l);
         store_owned(l, D, dx0, dy0, dpitch);
+        PF_STAMP(3 + 2 * l);
         // the next level reads D and overwrites S, which nobody reads any more
         const uint8_t* t = S;
         S = D;

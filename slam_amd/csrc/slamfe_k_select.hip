@@ -167,6 +167,153 @@ __global__ __launch_bounds__(256) void k_level_cut(slamfe_dev_geom g,
     if (tid < nb) band_off[(size_t)f * g.total_bands + g.lv[l].band_base + tid] = incl - cb;
 }
 
+// k_band_hist + k_level_cut as one launch for calls of a few frames: one
+// workgroup of 1024 threads per frame.  Pass 1 builds the eight level
+// histograms in LDS from every candidate list of the frame; a wavefront per
+// level then finds the level's cut; pass 2 counts every tile's kept candidates
+// into its band; a wavefront per level turns the band counts into offsets.
+// Outputs are those of k_level_cut (band_off, level_kept, level_cutoff).
+#define SELECT_PLAN_THREADS 1024
+#define SELECT_PLAN_MAX_TILES 8192
+#define SELECT_PLAN_MAX_BANDS 1024
+
+// Visit the keys of one tile's list: four 16-byte loads in flight at a time.
+template <class F>
+__device__ __forceinline__ void tile_keys(const uint32_t* __restrict__ list, uint32_t n, F fn)
+{
+    for (uint32_t k0 = 0; k0 < n; k0 += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = k0 + 4u * u < n ? *reinterpret_cast<const uint4*>(list + k0 + 4 * u) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t b = k0 + 4u * u;
+            if (b + 0 < n) fn(v[u].x);
+            if (b + 1 < n) fn(v[u].y);
+            if (b + 2 < n) fn(v[u].z);
+            if (b + 3 < n) fn(v[u].w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SELECT_PLAN_THREADS) void k_select_plan(slamfe_dev_geom g,
+                                                                      const uint32_t* __restrict__ cand,
+                                                                      const uint32_t* __restrict__ cand_cnt,
+                                                                      uint32_t* __restrict__ band_off,
+                                                                      uint32_t* __restrict__ level_kept,
+                                                                      int32_t* __restrict__ level_cutoff)
+{
+    __shared__ uint32_t hist[SLAMFE_MAX_LEVELS][256];
+    __shared__ uint32_t bkept[SELECT_PLAN_MAX_BANDS];
+    __shared__ int32_t cut_s[SLAMFE_MAX_LEVELS];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < SLAMFE_MAX_LEVELS * 256; i += SELECT_PLAN_THREADS) (&hist[0][0])[i] = 0;
+    for (int i = tid; i < g.total_bands; i += SELECT_PLAN_THREADS) bkept[i] = 0;
+    const size_t tbase = (size_t)f * g.total_tiles;
+    // the counts of this thread's tiles (tile = tid, tid + 1024, ...), fetched together
+    constexpr int TPT = SELECT_PLAN_MAX_TILES / SELECT_PLAN_THREADS;
+    uint32_t cnt[TPT];
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+        const int t = tid + u * SELECT_PLAN_THREADS;
+        cnt[u] = t < g.total_tiles ? cand_cnt[tbase + t] : 0u;
+    }
+    __syncthreads();
+    // ---- pass 1: level histograms
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+        const int t = tid + u * SELECT_PLAN_THREADS;
+        if (cnt[u] == 0) continue;
+        uint32_t* h = hist[find_level_by_tile(g, t)];
+        tile_keys(cand + (tbase + t) * SLAMFE_TILE_CAND, cnt[u], [&](uint32_t k) { atomicAdd(&h[SLAMFE_KEY_S(k)], 1u); });
+    }
+    __syncthreads();
+    // ---- the cut of every level: wavefront = level, lane l holds scores 255 - 4l .. 252 - 4l
+    // so that a prefix over the lanes is a suffix over the scores
+    if (wv < g.nlevels) {
+        const int l = wv, quota = g.lv[l].quota;
+        const uint32_t* h = hist[l];
+        const int s0 = 255 - 4 * lane; // the lane's highest score
+        const uint32_t b0 = h[s0], b1 = h[s0 - 1], b2 = h[s0 - 2], b3 = h[s0 - 3];
+        uint32_t incl = b0 + b1 + b2 + b3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        const uint32_t before = incl - (b0 + b1 + b2 + b3); // candidates with a score above the lane's
+        // suffix[s] for the lane's four scores
+        const uint32_t f0 = before + b0, f1 = f0 + b1, f2 = f1 + b2, f3 = f2 + b3;
+        // number of scores s with suffix[s] >= quota (suffix grows as s falls)
+        const uint32_t q = (uint32_t)max(quota, 0);
+        const int mine = (f0 >= q) + (f1 >= q) + (f2 >= q) + (f3 >= q);
+        const int c = wave_sum(mine);
+        int cut;
+        uint32_t kept;
+        if (total <= (uint32_t)max(quota, 0) || (quota > 0 && total <= (uint32_t)quota)) {
+            cut = 0;
+            kept = total;
+        } else if (quota <= 0) {
+            cut = 256;
+            kept = 0;
+        } else {
+            cut = c - 1;
+            // suffix[cut]: held by the lane whose scores include cut
+            const int owner = (255 - cut) >> 2, which = (255 - cut) & 3;
+            const uint32_t mysuf = which == 0 ? f0 : which == 1 ? f1 : which == 2 ? f2 : f3;
+            kept = (uint32_t)__shfl((int)mysuf, owner);
+        }
+        if (lane == 0) {
+            cut_s[l] = cut;
+            level_kept[f * SLAMFE_MAX_LEVELS + l] = kept;
+            level_cutoff[f * SLAMFE_MAX_LEVELS + l] = cut;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: kept candidates of every tile, summed per band
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+        const int t = tid + u * SELECT_PLAN_THREADS;
+        if (cnt[u] == 0) continue;
+        const int l = find_level_by_tile(g, t);
+        const int cut = cut_s[l];
+        uint32_t k = 0;
+        tile_keys(cand + (tbase + t) * SLAMFE_TILE_CAND, cnt[u], [&](uint32_t key) { k += (int)SLAMFE_KEY_S(key) >= cut; });
+        if (k) atomicAdd(&bkept[g.lv[l].band_base + (t - g.lv[l].tile_base) / g.lv[l].tiles_x], k);
+    }
+    __syncthreads();
+    // ---- band offsets inside each level: wavefront = level, four bands per lane and step
+    if (wv < g.nlevels) {
+        const int l = wv, nb = g.lv[l].tiles_y, bb = g.lv[l].band_base;
+        uint32_t carry = 0;
+        for (int b0 = 0; b0 < nb; b0 += 256) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = b0 + 4 * lane + k;
+                v[k] = b < nb ? bkept[bb + b] : 0u;
+            }
+            const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += o;
+            }
+            uint32_t off = carry + incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = b0 + 4 * lane + k;
+                if (b < nb) band_off[(size_t)f * g.total_bands + bb + b] = off;
+                off += v[k];
+            }
+            carry += (uint32_t)__shfl((int)incl, 63);
+        }
+    }
+}
+
 // Bitonic sort of 64 keys held one per lane, ascending by lane.
 __device__ __forceinline__ uint32_t wave_sort64(uint32_t v)
 {
@@ -316,12 +463,19 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
                          size_t sort_lds_bytes)
 {
-    hipLaunchKernelGGL(k_band_hist, frame_grid((g.total_bands + 3) / 4, nframes), dim3(256), 0, s, g,
-                       cand, cand_cnt, band_hist, nframes);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_level_cut, frame_grid(g.nlevels, nframes), dim3(256), 0, s, g, band_hist,
-                       band_off, level_kept, level_cutoff, nframes);
-    LAUNCH_CHECK();
+    if (nframes < 8 && g.total_tiles <= SELECT_PLAN_MAX_TILES && g.total_bands <= SELECT_PLAN_MAX_BANDS) {
+        // a few frames: histograms, cuts and band offsets in one launch
+        hipLaunchKernelGGL(k_select_plan, dim3(nframes), dim3(SELECT_PLAN_THREADS), 0, s, g, cand, cand_cnt,
+                           band_off, level_kept, level_cutoff);
+        LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_band_hist, frame_grid((g.total_bands + 3) / 4, nframes), dim3(256), 0, s, g,
+                           cand, cand_cnt, band_hist, nframes);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_level_cut, frame_grid(g.nlevels, nframes), dim3(256), 0, s, g, band_hist,
+                           band_off, level_kept, level_cutoff, nframes);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_select_write, frame_grid((g.total_bands + 3) / 4, nframes), dim3(256), sort_lds_bytes,
                        s, g, cand, cand_cnt, band_off, level_kept, level_cutoff, slot_base, nslots,
                        kp_key, kp_level, kp_count, max_kp, nframes);
