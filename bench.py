@@ -263,6 +263,7 @@ def leg_host_path(local_rank):
                              "what": "slamfe_extract_batch: 64 pageable 640x480 frames in, keypoints + "
                                      "descriptors back to host memory (PCIe both ways)"}
     single = {}
+    native = os.path.join(ROOT, "tools", "single_call_bench")
     cases = (("vga_orb_2000_thr20", W, H, NFEAT, THR, abi.MODE_ORB),
              ("kitti_1241x376_provided_thr30", 1241, 376, 10000, 30, abi.MODE_PROVIDED),
              ("kitti_1241x376_orb_3000_thr20", 1241, 376, 3000, 20, abi.MODE_ORB))
@@ -282,7 +283,26 @@ def leg_host_path(local_rank):
             single[name] = {"extract_ms": round(ext_med, 4), "extract_mean_ms": round(ext_mean, 4),
                             "extract_plus_match_ms": round(loop_med, 4),
                             "extract_plus_match_mean_ms": round(loop_mean, 4),
-                            "frames_per_s": round(1e3 / loop_mean, 1), "keypoints": int(hc.counts[0])}
+                            "frames_per_s": round(1e3 / loop_mean, 1), "keypoints": int(hc.counts[0]),
+                            "caller": "python (ctypes)"}
+        # the same two loops from a C program (no interpreter between the calls): what
+        # the reference's C++ host would see
+        if os.path.exists(native):
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                fa, fb = os.path.join(td, "a.raw"), os.path.join(td, "b.raw")
+                a.tofile(fa)
+                b.tofile(fb)
+                r = subprocess.run([native, fa, fb, str(w), str(h), str(mode), str(thr), str(nf), "200"],
+                                   capture_output=True, text=True, timeout=120)
+            if r.returncode == 0:
+                c = json.loads(r.stdout.strip().splitlines()[-1])
+                c["frames_per_s"] = round(1e3 / c["extract_plus_match_mean_ms"], 1)
+                c["caller"] = "C (tools/single_call_bench.c)"
+                single[name + "_c_caller"] = c
+            else:
+                single[name + "_c_caller"] = {"error": r.stderr[-300:]}
     out["single_call_ms"] = single
     return out
 

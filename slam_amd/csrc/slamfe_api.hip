@@ -35,6 +35,7 @@
 
 // Calls with fewer frames than this take the fused, launch-poor kernels.
 #define SLAMFE_FEW_FRAMES 8
+#define SLAMFE_FEW_PIXELS 2200000 /* ... and at most this many pixels in the call */
 
 namespace {
 
@@ -104,6 +105,7 @@ struct slamfe_ctx {
     Scratch rp_uv_all, rp_mask, rp_off, rp_total, vis_uv, vis_idx;
     Scratch tri_in, tri_out;
     int vis_count = -1;
+    long long few_pixels = SLAMFE_FEW_PIXELS;
     void* static_scratch = nullptr; // this GPU's copy of `scratch` (device address)
     // in-pipeline stage probe (slamfe_debug_probe): events around one stage of
     // every extraction / batched match that is queued while the probe is set
@@ -444,6 +446,14 @@ int slot_of(const slamfe_ctx* c, uint64_t handle)
     return c->slot_handle[s] == handle ? s : -1;
 }
 
+// Does a call of n frames of w x h take the launch-poor kernels?  Only where the
+// whole call is small enough to be bound by launch latency: large frames fill
+// the chip on their own and the throughput kernels are faster there.
+bool is_few(const slamfe_ctx* c, int n, int w, int h)
+{
+    return n < SLAMFE_FEW_FRAMES && (long long)n * w * h <= c->few_pixels;
+}
+
 // Queue the whole extraction of n device-resident frames.
 // d_imgs == nullptr: level 0 of the pyramid has already been written (scaled ingest).
 int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int stride,
@@ -472,7 +482,7 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     // Calls of a few frames are bound by the chain of dependent launches, not by
     // the arithmetic: they take the fused kernels (fewer launches, some redundant
     // work); batches take the throughput kernels.  Results are identical.
-    const bool few = n < SLAMFE_FEW_FRAMES;
+    const bool few = is_few(c, n, w, h);
     if (few && g.pt_x > 0) {
         ProbeScope ps(c, SLAMFE_STAGE_PYRAMID);
         KCHK(c, slamfe_launch_pyramid_fused(s, g, n, d_imgs, stride, frame_stride, channels, c->pyr, c->taps));
@@ -492,7 +502,7 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
         ProbeScope ps(c, SLAMFE_STAGE_SELECT);
         KCHK(c, slamfe_launch_select(s, g, n, c->cand, c->cand_cnt, c->band_hist, c->band_off,
                                      c->level_kept, c->level_cutoff, slot_base, c->nslots, c->kp_key,
-                                     c->kp_level, c->kp_count, c->max_kp, c->sort_lds));
+                                     c->kp_level, c->kp_count, c->max_kp, c->sort_lds, few));
     }
     if (few) {
         ProbeScope ps(c, SLAMFE_STAGE_DESCRIBE);
@@ -716,6 +726,7 @@ int slamfe_create(const slamfe_params* pin, slamfe_ctx** out)
     c->nslots = p.frame_slots;
     c->slot_handle.assign((size_t)c->nslots, 0);
     c->slot_count_host.assign((size_t)c->nslots, -1);
+    if (const char* e = getenv("SLAMFE_FEW_PIXELS")) c->few_pixels = atoll(e); // tuning aid
     *out = c; // returned even on failure so that slamfe_last_error can be read
     if (p.stream) {
         c->stream = (hipStream_t)p.stream;
@@ -928,7 +939,8 @@ int slamfe_extract_scaled_bgr(slamfe_ctx* c, const uint8_t* bgr, int w, int h, i
         HIPCHK(c, hipMemcpyAsync(c->h_pin + tap_bytes, c->ing_bgr.p, (size_t)bpitch * dh,
                                  hipMemcpyDeviceToHost, s));
     int slot = slot_of(c, hd);
-    rc = download_frames(c, &slot, 1, kps, desc, cap, n_out);
+    rc = c->max_kp % 4 == 0 ? export_frames(c, &slot, 1, kps, desc, cap, n_out)
+                            : download_frames(c, &slot, 1, kps, desc, cap, n_out);
     if (resized_bgr)
         for (int y = 0; y < dh; ++y)
             memcpy(resized_bgr + (size_t)y * dw * 3, c->h_pin + tap_bytes + (size_t)y * bpitch, (size_t)dw * 3);
@@ -1441,7 +1453,7 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
         case SLAMFE_STAGE_SELECT:
             KCHK(c, slamfe_launch_select(s, g, nframes, c->cand, c->cand_cnt, c->band_hist, c->band_off,
                                          c->level_kept, c->level_cutoff, slot_base, c->nslots,
-                                         c->kp_key, c->kp_level, c->kp_count, c->max_kp, c->sort_lds));
+                                         c->kp_key, c->kp_level, c->kp_count, c->max_kp, c->sort_lds, false));
             break;
         case SLAMFE_STAGE_ORIENT:
             KCHK(c, slamfe_launch_orient(s, g, nframes, c->pyr, slot_base, c->nslots, c->kp_key,

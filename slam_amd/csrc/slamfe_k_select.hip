@@ -461,9 +461,9 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          const uint32_t* cand_cnt, uint32_t* band_hist, uint32_t* band_off,
                          uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
-                         size_t sort_lds_bytes)
+                         size_t sort_lds_bytes, bool few)
 {
-    if (nframes < 8 && g.total_tiles <= SELECT_PLAN_MAX_TILES && g.total_bands <= SELECT_PLAN_MAX_BANDS) {
+    if (few && g.total_tiles <= SELECT_PLAN_MAX_TILES && g.total_bands <= SELECT_PLAN_MAX_BANDS) {
         // a few frames: histograms, cuts and band offsets in one launch
         hipLaunchKernelGGL(k_select_plan, dim3(nframes), dim3(SELECT_PLAN_THREADS), 0, s, g, cand, cand_cnt,
                            band_off, level_kept, level_cutoff);

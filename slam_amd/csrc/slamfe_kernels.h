@@ -28,7 +28,7 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          const uint32_t* cand_cnt, uint32_t* band_hist, uint32_t* band_off,
                          uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
-                         size_t sort_lds_bytes);
+                         size_t sort_lds_bytes, bool few /* one-launch plan kernel */);
 int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
                          int slot_base, int nslots, const uint32_t* kp_key, const uint32_t* kp_level,
                          const int32_t* kp_count, int32_t* kp_mom, slamfe_keypoint* kps, float* kp_rot,
