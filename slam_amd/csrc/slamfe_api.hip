@@ -1049,13 +1049,34 @@ int slamfe_match_frames(slamfe_ctx* c, uint64_t query_frame, uint64_t train_fram
 {
     if (!c) return SLAMFE_E_INVALID;
     HIPCHK(c, hipSetDevice(c->p.device_id));
+    const int sq = slot_of(c, query_frame);
+    if (sq < 0 || slot_of(c, train_frame) < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown");
+    // The query frame's keypoint count is known on the host if the frame came
+    // through a host-pointer call.  Then the rows are written by the merge kernel
+    // straight into pinned host memory (which the device can address): one launch
+    // sequence, one wait.
+    int32_t nq = c->slot_count_host[(size_t)sq];
+    if (out && nq >= 0) {
+        if (nq > c->max_kp) nq = c->max_kp;
+        if (nq_out) *nq_out = nq;
+        if (nq > cap)
+            return fail(c, SLAMFE_E_CAPACITY, "%d match rows exceed the caller's capacity %d", nq, cap);
+        int rc = pin_reserve(c, (size_t)c->max_kp * sizeof *out);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // the bounce buffer may still be in use
+        if ((rc = slamfe_match_resident(c, query_frame, train_frame, reinterpret_cast<slamfe_match2*>(c->h_pin))))
+            return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (nq > 0) memcpy(out, c->h_pin, (size_t)nq * sizeof *out);
+        return SLAMFE_OK;
+    }
     int rc = slamfe_match_resident(c, query_frame, train_frame, c->match_out);
     if (rc) return rc;
-    int sq = slot_of(c, query_frame);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->kp_count + sq, sizeof(int32_t), hipMemcpyDeviceToHost,
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int32_t nq = c->h_cnt[0];
+    nq = c->h_cnt[0];
+    c->slot_count_host[(size_t)sq] = nq;
     if (nq > c->max_kp) nq = c->max_kp;
     if (nq_out) *nq_out = nq;
     if (out) {
