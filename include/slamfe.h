@@ -24,6 +24,33 @@
  *     the front-end only from the processFrames thread, Init.cc:83).
  *   - Pointers named d_* are device pointers on the context's GPU; all others
  *     are host pointers.
+ *   - Stream ordering.  Every call runs on the context's stream (params.stream,
+ *     or a stream the context creates).  Calls that take only host pointers are
+ *     synchronous: they return after their results have been copied out.  Calls
+ *     documented as asynchronous only queue work on that stream.  For every d_*
+ *     argument the caller orders its own accesses against that stream:
+ *       inputs  (d_imgs, d_query, d_train, d_keys_all): what the caller wrote
+ *               must be complete before the call is made -- written on the
+ *               context's stream itself, or followed by a synchronisation of the
+ *               writing stream (or an event the context's stream waits on) -- and
+ *               must not be overwritten until the queued work has run;
+ *       outputs (d_out, d_keys): must not be touched by other streams from the
+ *               call until the queued work has run (a fill of d_out queued on
+ *               another stream and not waited for races with the library's
+ *               writes); they may be read after slamfe_sync, or by work queued
+ *               later on the context's stream.
+ *     The library never synchronises with other streams on its own.
+ *   - Keypoint order and capacity.  In SLAMFE_MODE_ORB keypoints come in the
+ *     canonical order (level, y, x); cv::ORB's own order after retainBest is
+ *     implementation-defined (std::nth_element), so only the keypoint *set* is
+ *     comparable with an OpenCV build, and train indices / tie-breaks downstream
+ *     follow the canonical order.  SLAMFE_MODE_PROVIDED keeps FAST's raster order,
+ *     as the reference's calls do.  retainBest keeps every tie at the cut-off
+ *     score, so a frame can yield more than max_keypoints keypoints: the
+ *     host-pointer calls then return SLAMFE_E_CAPACITY; on the resident path the
+ *     frame is truncated to its first max_keypoints keypoints in that order (the
+ *     device-side count keeps the untruncated number, see
+ *     slamfe_frame_device_ptrs) and the match calls use the truncated frame.
  */
 #ifndef SLAMFE_H
 #define SLAMFE_H
@@ -157,7 +184,9 @@ int slamfe_extract_scaled_bgr(slamfe_ctx* ctx, const uint8_t* bgr, int w, int h,
 
 /* Init.cc:75-78 for frames that already sit in device memory (frame i at
  * d_imgs + i*frame_stride_bytes).  Asynchronous on the context's stream; no
- * host synchronisation.  Results stay device-resident under the handles. */
+ * host synchronisation.  Results stay device-resident under the handles.
+ * d_imgs must be complete when the call is made and stay unchanged until the
+ * queued work has run (see "Stream ordering" above). */
 int slamfe_extract_resident(slamfe_ctx* ctx, const void* d_imgs, int n, int w, int h, int stride,
                             size_t frame_stride_bytes, int channels, uint64_t* frame_handles);
 
@@ -172,13 +201,17 @@ int slamfe_frame_download(slamfe_ctx* ctx, uint64_t frame_handle, slamfe_keypoin
 int slamfe_match_knn2(slamfe_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
                       slamfe_match2* out);
 
-/* Init.cc:131-153 on two device-resident frames; out may be NULL (result stays on the
- * device, readable with slamfe_match_download).  *nq_out = rows written. */
+/* Init.cc:131-153 on two device-resident frames: rows to out[0 .. *nq_out), at
+ * most cap.  out may be NULL: then only *nq_out (the query frame's keypoint
+ * count) is returned; callers that want the rows on the device use
+ * slamfe_match_resident with a buffer of their own. */
 int slamfe_match_frames(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
                         slamfe_match2* out, int cap, int* nq_out);
 
 /* Asynchronous form of Init.cc:131-153: both frames device-resident, result written to
- * d_out[0..max_keypoints) (device memory), row counts read on the device. */
+ * d_out[0..max_keypoints) (device memory), row counts read on the device.  Rows
+ * beyond the query frame's count are left untouched.  d_out must not be written
+ * by another stream while the queued work runs (see "Stream ordering" above). */
 int slamfe_match_resident(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
                           slamfe_match2* d_out);
 
@@ -284,7 +317,9 @@ int slamfe_sync(slamfe_ctx* ctx);
 
 /* No counterpart in the reference: device pointers of a resident frame (valid until the slot is recycled after
  * frame_slots further frames): keypoints, 32-byte descriptor rows, and the
- * device-side count. */
+ * device-side count.  *d_count may exceed max_keypoints: the frame then holds
+ * only its first max_keypoints keypoints in (level, y, x) order (ties at the
+ * retain-best cut-off overflowed the slot); readers clamp the count. */
 int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamfe_keypoint** d_kps,
                              const uint8_t** d_desc, const int32_t** d_count);
 

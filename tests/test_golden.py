@@ -130,6 +130,25 @@ def test_cxx_host_adapter_against_checker(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cxx_tracking_loop_replay_against_checker(tmp_path):
+    # tests/cpp/test_tracking_loop.cpp: 40 frames of the reference's per-frame loop
+    # (Init.cc:118-328) through the C++ host layer with a growing map, rewritten
+    # coordinates every 10 frames and a wrapping frame-slot ring; every per-frame
+    # product equals the CPU checker's
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_tracking_loop")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    n, w, h = 40, 320, 240
+    frames = synth.frame_stream(w, h, n, seed=15)  # pans 3 px right, 2 px down per frame
+    path = tmp_path / "frames.raw"
+    frames.tofile(path)
+    r = subprocess.run([exe, str(path), str(w), str(h), str(n), "3", "2"], capture_output=True, timeout=110)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert b"tracking loop ok" in r.stdout
+
+
+@pytest.mark.gpu
 def test_c_caller_of_batch_entry_points():
     # tests/cpp/abi_batch_check.c: batch, per-frame, download and match calls agree
     # bit for bit and the error paths answer as the header documents
