@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void k_level_cut(slamfe_dev_geom g,
     if (tid < nb) band_off[(size_t)f * g.total_bands + g.lv[l].band_base + tid] = incl - cb;
 }
 
-// k_band_hist + k_level_cut as one launch for calls of a few frames: one
-// workgroup of 1024 threads per frame.  Pass 1 builds the eight level
+// k_band_hist + k_level_cut as one launch: one workgroup of 1024 threads per frame
+// (frames of at most SELECT_PLAN_MAX_TILES tiles; larger ones take the two kernels).  Pass 1 builds the eight level
 // histograms in LDS from every candidate list of the frame; a wavefront per
 // level then finds the level's cut; pass 2 counts every tile's kept candidates
 // into its band; a wavefront per level turns the band counts into offsets.
@@ -463,8 +463,12 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
                          uint32_t* kp_key, uint32_t* kp_level, int32_t* kp_count, int max_kp,
                          size_t sort_lds_bytes, bool few)
 {
-    if (few && g.total_tiles <= SELECT_PLAN_MAX_TILES && g.total_bands <= SELECT_PLAN_MAX_BANDS) {
-        // a few frames: histograms, cuts and band offsets in one launch
+    (void)few;
+    if (g.total_tiles <= SELECT_PLAN_MAX_TILES && g.total_bands <= SELECT_PLAN_MAX_BANDS) {
+        // histograms, cuts and band offsets in one launch, one workgroup per frame
+        // (frames up to about 1920 x 1080; measured on MI355X, 256 frames of 640 x 480:
+        // 0.054 ms against 0.091 ms for the three-launch form, which moves a
+        // histogram per tile row through memory)
         hipLaunchKernelGGL(k_select_plan, dim3(nframes), dim3(SELECT_PLAN_THREADS), 0, s, g, cand, cand_cnt,
                            band_off, level_kept, level_cutoff);
         LAUNCH_CHECK();
