@@ -374,7 +374,8 @@ void build_geometry(const slamfe_params& p, int w, int h, slamfe_dev_geom* g,
         L.pitch = (L.w + 63) / 64 * 64;
         L.quota = quota[l];
         L.off = off;
-        off += (uint32_t)L.pitch * (uint32_t)L.h;
+        // rows rounded up to 8: the blurred level is stored in tiles of 16 x 8 pixels
+        off += (uint32_t)L.pitch * (uint32_t)((L.h + 7) & ~7);
         off = (off + 255u) & ~255u;
         L.tiles_x = (L.w + SLAMFE_TILE_W - 1) / SLAMFE_TILE_W;
         L.tiles_y = (L.h + SLAMFE_TILE_H - 1) / SLAMFE_TILE_H;
@@ -1531,8 +1532,19 @@ int slamfe_debug_read_level(slamfe_ctx* c, int frame_in_batch, int level, int bl
         return fail(c, SLAMFE_E_CAPACITY, "level needs %d bytes", L.w * L.h);
     const uint8_t* src = (blurred ? c->blur : c->pyr) + (size_t)frame_in_batch * c->geom.frame_bytes + L.off;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, src, (size_t)L.pitch, (size_t)L.w, (size_t)L.h,
-                          hipMemcpyDeviceToHost));
+    if (!blurred) {
+        HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, src, (size_t)L.pitch, (size_t)L.w, (size_t)L.h,
+                              hipMemcpyDeviceToHost));
+        return SLAMFE_OK;
+    }
+    // the blurred level is tiled: 16 x 8 pixels per 128-byte tile, tiles row-major
+    const size_t rows8 = (size_t)((L.h + 7) & ~7);
+    std::vector<uint8_t> tiled((size_t)L.pitch * rows8);
+    HIPCHK(c, hipMemcpy(tiled.data(), src, tiled.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; ++y)
+        for (int x = 0; x < L.w; ++x)
+            out[(size_t)y * L.w + x] =
+                tiled[((size_t)(y >> 3) * (size_t)(L.pitch >> 4) + (size_t)(x >> 4)) * 128 + (size_t)(y & 7) * 16 + (size_t)(x & 15)];
     return SLAMFE_OK;
 }
 

@@ -181,26 +181,25 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
 //     desc->compute, Init.cc:78).  Lane i of a wavefront evaluates tests i,
 //     64+i, 128+i, 192+i, so each wave ballot is 8 descriptor bytes.
 // ---------------------------------------------------------------------------
-#define DP_ROWS 37 /* samples reach +-18 px (|pattern| <= 13 * sqrt 2 = 18.4) */
-#define DP_PC 3    /* 37 bytes from column cx-18, read as three 16-byte pieces */
-#define DP_PITCH (16 * DP_PC) /* bytes of a patch row in LDS */
+// The blurred level is stored in tiles of 16 x 8 pixels, one 128-byte line each.
+// A keypoint's samples reach +-18 px (|pattern| <= 13 * sqrt 2 = 18.4), a square
+// of 37 x 37 pixels that lies in at most 4 x 6 tiles: the wave fetches those
+// tiles whole (8 lanes x 16 bytes = one line) into an LDS image of 48 rows x 64
+// bytes, in which the keypoint sits at (cy - 8 * first tile row, cx - 16 * first
+// tile column).  (A row-major level costs about 51 lines per keypoint -- 37 rows
+// of 48 bytes at an arbitrary offset -- against 18 here.)
+#define DP_TCOLS 4
+#define DP_TROWS 6
+#define DP_PITCH (16 * DP_TCOLS)           /* bytes of a patch row in LDS */
+#define DP_LDS_ROWS (8 * DP_TROWS)
+#define DP_PIECES (DP_TCOLS * DP_TROWS * 8) /* 16-byte pieces of the largest tile region */
 
-// A wavefront walks keypoints idx = wave, wave + nwaves, ...  For each one it
-// stages the 37-row neighbourhood (rows of 40 bytes starting at cx-18,
-// unaligned dword loads) in its own LDS slice and gathers the 512 samples from
-// there.  Per-lane constants (the lane's four tests as floats, its staging
-// tasks) are set up once per wave.  The rotation is evaluated on float pairs
-// (x, y) = P * (a, b) + Q * (-b, a): the same products and one sum per
-// coordinate as the scalar expressions x = px*a - py*b, y = px*b + py*a, so the
-// bits are identical.  Rounding to the nearest integer (ties to even, as
-// cvRound) is the addition of 1.5 * 2^23, which leaves the integer in the low
-// mantissa bits.
 typedef float desc_v2f __attribute__((ext_vector_type(2)));
-#define DP_NIT ((DP_ROWS * DP_PC + 63) / 64)
+#define DP_NIT (DP_PIECES / 64)
 
 struct describe_lane {
     desc_v2f P[4][2], Q[4][2];
-    int trow[DP_NIT], tcol[DP_NIT];
+    int tcol[DP_NIT], trow[DP_NIT], trw[DP_NIT]; // piece `it` of the lane: tile column, tile row, row inside the tile
 };
 
 __device__ __forceinline__ describe_lane describe_setup(int lane)
@@ -214,44 +213,58 @@ __device__ __forceinline__ describe_lane describe_setup(int lane)
         D.P[j][1] = (desc_v2f){(float)t[2], (float)t[2]};
         D.Q[j][1] = (desc_v2f){(float)t[3], (float)t[3]};
     }
-    // The patch is fetched in 16-byte pieces (unaligned in memory): the kernel's
-    // time is the address unit's, which spends about as long on a wave's dword
-    // loads as on its 16-byte loads.
 #pragma unroll
     for (int it = 0; it < DP_NIT; ++it) {
-        const int t = it * 64 + lane, row = t / DP_PC;
-        D.trow[it] = row < DP_ROWS ? row : 0;
-        D.tcol[it] = 16 * (t - row * DP_PC);
+        const int p = it * 64 + lane, t = p >> 3; // eight consecutive lanes fetch one tile = one line
+        D.tcol[it] = t % DP_TCOLS;
+        D.trow[it] = t / DP_TCOLS;
+        D.trw[it] = p & 7;
     }
     return D;
 }
 
-// The lane's pieces of the patch whose top-left corner is `base` (= centre - 18, - 18).
-// (The last piece of a row reaches 8 bytes past the 40 that are used: into the
-// row's padding or the next row, always inside the pyramid buffer.)
-__device__ __forceinline__ void describe_load(const describe_lane& D, const uint8_t* __restrict__ base, int pitch,
-                                              int lane, uint4 (&r)[DP_NIT])
+// The tiles that hold columns cx-18 .. cx+18 and rows cy-18 .. cy+18 of a tiled level.
+struct describe_region {
+    int tx0, ty0, ncols, nrows;
+};
+
+__device__ __forceinline__ describe_region describe_region_of(int cx, int cy)
+{
+    describe_region R;
+    R.tx0 = (cx - 18) >> 4;
+    R.ty0 = (cy - 18) >> 3;
+    R.ncols = ((cx + 18) >> 4) - R.tx0 + 1; // 3 or 4
+    R.nrows = ((cy + 18) >> 3) - R.ty0 + 1; // 5 or 6
+    return R;
+}
+
+// The lane's pieces of the tile region; level = first byte of the tiled level,
+// tpr = tiles per tile row (= level pitch / 16).
+__device__ __forceinline__ void describe_load(const describe_lane& D, const uint8_t* __restrict__ level, int tpr,
+                                              const describe_region& R, uint4 (&r)[DP_NIT])
 {
 #pragma unroll
     for (int it = 0; it < DP_NIT; ++it) {
         r[it] = make_uint4(0, 0, 0, 0);
-        if (it < DP_NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC)
-            __builtin_memcpy(&r[it], base + D.trow[it] * pitch + D.tcol[it], 16);
+        if (D.tcol[it] < R.ncols && D.trow[it] < R.nrows)
+            r[it] = *reinterpret_cast<const uint4*>(level + ((size_t)(R.ty0 + D.trow[it]) * tpr + R.tx0 + D.tcol[it]) * 128 +
+                                                    D.trw[it] * 16);
     }
 }
 
-// Stage the pieces in the wave's LDS slice, rotate the pattern by (cos, sin) = rot,
+// Stage the pieces in the wave's LDS image, rotate the pattern by (cos, sin) = rot,
 // compare the 256 sample pairs; lanes 0..3 store the 32 descriptor bytes.
 __device__ __forceinline__ void describe_finish(const describe_lane& D, const uint4 (&r)[DP_NIT], uint4* my,
-                                                float2 rot, int lane, uint8_t* __restrict__ out32)
+                                                const describe_region& R, int cx, int cy, float2 rot, int lane,
+                                                uint8_t* __restrict__ out32)
 {
 #pragma unroll
     for (int it = 0; it < DP_NIT; ++it)
-        if (it < DP_NIT - 1 || it * 64 + lane < DP_ROWS * DP_PC) my[it * 64 + lane] = r[it];
+        if (D.tcol[it] < R.ncols && D.trow[it] < R.nrows) my[(D.trow[it] * 8 + D.trw[it]) * DP_TCOLS + D.tcol[it]] = r[it];
     // only this wavefront reads what it wrote: LDS operations of one wave are
     // ordered, the fences keep the compiler from moving accesses across
     wave_lds_fence();
-    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + 18 * DP_PITCH + 18;
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + (cy - 8 * R.ty0) * DP_PITCH + (cx - 16 * R.tx0);
     const desc_v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
     const desc_v2f magic = {12582912.f, 12582912.f};
     unsigned long long word[4];
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   const float2* __restrict__ kp_rot,
                                                   uint8_t* __restrict__ desc, int max_kp, int nframes)
 {
-    __shared__ uint4 patch128[4][DP_ROWS * DP_PC];
+    __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_TCOLS];
     const int f = wg_frame();
     if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
@@ -315,10 +328,10 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
         const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
         const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
         if (cx < 18 || cy < 18 || cx >= w - 22 || cy >= h - 18) continue; // reads must stay inside
-        const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 18) * pitch + (cx - 18);
+        const describe_region R = describe_region_of(cx, cy);
         uint4 r[DP_NIT];
-        describe_load(D, base, pitch, lane, r);
-        describe_finish(D, r, my, rot, lane, desc + ((size_t)slot * max_kp + idx) * 32);
+        describe_load(D, frame + g.lv[l].off, pitch >> 4, R, r);
+        describe_finish(D, r, my, R, cx, cy, rot, lane, desc + ((size_t)slot * max_kp + idx) * 32);
     }
 }
 
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
                                                          float2* __restrict__ kp_rot, uint8_t* __restrict__ desc,
                                                          int max_kp, int mode, int patch_size, int nframes)
 {
-    __shared__ uint4 patch128[4][DP_ROWS * DP_PC];
+    __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_TCOLS];
     const int f = wg_frame();
     if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
@@ -373,7 +386,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
         uint4 x4 = make_uint4(0, 0, 0, 0);
         uint4 r[DP_NIT];
         if (can_orient) x4 = orient_load(W, pyr + lvl + (size_t)(cy - 15) * pitch + (cx - 15), pitch, lane);
-        if (can_describe) describe_load(D, blur + lvl + (size_t)(cy - 18) * pitch + (cx - 18), pitch, lane, r);
+        const describe_region R = describe_region_of(cx, cy);
+        if (can_describe) describe_load(D, blur + lvl, pitch >> 4, R, r);
         int2 m = make_int2(0, 0);
         if (can_orient) {
             orient_moments(W, x4, m.x, m.y);
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
             kps[e] = k;
             kp_rot[e] = rot;
         }
-        if (can_describe) describe_finish(D, r, my, rot, lane, desc + e * 32);
+        if (can_describe) describe_finish(D, r, my, R, cx, cy, rot, lane, desc + e * 32);
     }
 }
 

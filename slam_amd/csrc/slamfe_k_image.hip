@@ -790,11 +790,15 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                 uint32_t hi = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
                 return lo | hi;
             };
-            uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off + (size_t)gy * L.pitch + gx;
-            // rows are padded to a multiple of 64 bytes, so the dword store stays
-            // inside the row even when it covers pixels beyond w
+            // The blurred level is stored in tiles of 16 x 8 pixels (one 128-byte line
+            // each, tiles row-major): the descriptor kernel fetches a keypoint's
+            // neighbourhood as whole lines.  gy is even, so both rows lie in one tile;
+            // rows are padded to a multiple of 64 bytes and the level to a multiple
+            // of 8 rows, so stores that cover pixels beyond w stay inside the level.
+            uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off +
+                           ((size_t)(gy >> 3) * (size_t)(L.pitch >> 4) + (size_t)(gx >> 4)) * 128 + (gy & 7) * 16 + (gx & 15);
             *reinterpret_cast<uint32_t*>(out) = pack(e);
-            if (gy + 1 < L.h) *reinterpret_cast<uint32_t*>(out + L.pitch) = pack(o);
+            if (gy + 1 < L.h) *reinterpret_cast<uint32_t*>(out + 16) = pack(o);
         }
     }
     __syncthreads();
