@@ -105,6 +105,9 @@ struct slamfe_ctx {
     Scratch rp_uv_all, rp_mask, rp_off, rp_total, vis_uv, vis_idx;
     Scratch tri_in, tri_out;
     int vis_count = -1;
+    // where level 0 of the most recent extraction lives (the pyramid buffer, or the
+    // caller's frames used in place)
+    slamfe_level0 cur_l0 = {nullptr, 0};
     long long few_pixels = SLAMFE_FEW_PIXELS;
     void* static_scratch = nullptr; // this GPU's copy of `scratch` (device address)
     // in-pipeline stage probe (slamfe_debug_probe): events around one stage of
@@ -484,20 +487,31 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
     // the arithmetic: they take the fused kernels (fewer launches, some redundant
     // work); batches take the throughput kernels.  Results are identical.
     const bool few = is_few(c, n, w, h);
+    c->cur_l0.base = c->pyr + g.lv[0].off;
+    c->cur_l0.frame_stride = g.frame_bytes;
     if (few && g.pt_x > 0) {
         ProbeScope ps(c, SLAMFE_STAGE_PYRAMID);
         KCHK(c, slamfe_launch_pyramid_fused(s, g, n, d_imgs, stride, frame_stride, channels, c->pyr, c->taps));
     } else {
-        if (d_imgs)
+        // Gray frames whose rows already have level 0's pitch are used in place:
+        // the kernels that read level 0 take its address from cur_l0, and the copy
+        // into the pyramid buffer (78 MB each way per 256 VGA frames) is skipped.
+        const bool in_place = d_imgs && channels == 1 && stride == g.lv[0].pitch &&
+                              (uintptr_t)d_imgs % 16 == 0 && frame_stride % 16 == 0;
+        if (in_place) {
+            c->cur_l0.base = d_imgs;
+            c->cur_l0.frame_stride = frame_stride;
+        } else if (d_imgs) {
             KCHK(c, slamfe_launch_ingest(s, d_imgs, w, h, stride, frame_stride, channels, n, c->pyr,
                                          g.frame_bytes, g.lv[0].pitch));
+        }
         ProbeScope ps(c, SLAMFE_STAGE_PYRAMID);
-        KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps));
+        KCHK(c, slamfe_launch_pyramid(s, g, n, c->pyr, c->taps, c->cur_l0));
     }
     {
         ProbeScope ps(c, SLAMFE_STAGE_FAST);
         KCHK(c, slamfe_launch_fast_blur(s, g, n, c->pyr, c->blur, c->p.fast_threshold,
-                                        c->p.edge_threshold, c->cand, c->cand_cnt));
+                                        c->p.edge_threshold, c->cand, c->cand_cnt, c->cur_l0));
     }
     {
         ProbeScope ps(c, SLAMFE_STAGE_SELECT);
@@ -516,7 +530,7 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
         ProbeScope ps(c, SLAMFE_STAGE_ORIENT);
         KCHK(c, slamfe_launch_orient(s, g, n, c->pyr, slot_base, c->nslots, c->kp_key, c->kp_level,
                                      c->kp_count, c->kp_mom, c->kps, c->kp_rot, c->max_kp, c->p.mode,
-                                     c->p.patch_size));
+                                     c->p.patch_size, c->cur_l0));
     }
     {
         ProbeScope ps(c, SLAMFE_STAGE_DESCRIBE);
@@ -1466,11 +1480,11 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
     for (int r = 0; r < reps; ++r) {
         switch (stage) {
         case SLAMFE_STAGE_PYRAMID:
-            KCHK(c, slamfe_launch_pyramid(s, g, nframes, c->pyr, c->taps));
+            KCHK(c, slamfe_launch_pyramid(s, g, nframes, c->pyr, c->taps, c->cur_l0));
             break;
         case SLAMFE_STAGE_FAST:
             KCHK(c, slamfe_launch_fast_blur(s, g, nframes, c->pyr, c->blur, c->p.fast_threshold,
-                                            c->p.edge_threshold, c->cand, c->cand_cnt));
+                                            c->p.edge_threshold, c->cand, c->cand_cnt, c->cur_l0));
             break;
         case SLAMFE_STAGE_SELECT:
             KCHK(c, slamfe_launch_select(s, g, nframes, c->cand, c->cand_cnt, c->band_hist, c->band_off,
@@ -1480,7 +1494,7 @@ int slamfe_debug_time_stage(slamfe_ctx* c, int stage, int nframes, int reps, flo
         case SLAMFE_STAGE_ORIENT:
             KCHK(c, slamfe_launch_orient(s, g, nframes, c->pyr, slot_base, c->nslots, c->kp_key,
                                          c->kp_level, c->kp_count, c->kp_mom, c->kps, c->kp_rot,
-                                         c->max_kp, c->p.mode, c->p.patch_size));
+                                         c->max_kp, c->p.mode, c->p.patch_size, c->cur_l0));
             break;
         case SLAMFE_STAGE_DESCRIBE:
             KCHK(c, slamfe_launch_describe(s, g, nframes, c->blur, slot_base, c->nslots, c->kp_key,
@@ -1531,6 +1545,8 @@ int slamfe_debug_read_level(slamfe_ctx* c, int frame_in_batch, int level, int bl
     if ((size_t)L.w * L.h > (size_t)out_capacity)
         return fail(c, SLAMFE_E_CAPACITY, "level needs %d bytes", L.w * L.h);
     const uint8_t* src = (blurred ? c->blur : c->pyr) + (size_t)frame_in_batch * c->geom.frame_bytes + L.off;
+    if (!blurred && level == 0 && c->cur_l0.base) // possibly the caller's frames, used in place
+        src = c->cur_l0.base + (size_t)frame_in_batch * c->cur_l0.frame_stride;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!blurred) {
         HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, src, (size_t)L.pitch, (size_t)L.w, (size_t)L.h,

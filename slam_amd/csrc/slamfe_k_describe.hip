@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
                                                 const uint32_t* __restrict__ kp_key,
                                                 const uint32_t* __restrict__ kp_level,
                                                 const int32_t* __restrict__ kp_count,
-                                                int2* __restrict__ kp_mom, int max_kp, int nframes)
+                                                int2* __restrict__ kp_mom, int max_kp, int nframes,
+                                                slamfe_level0 l0)
 {
     const int f = wg_frame();
     if (f >= nframes) return;
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void k_orient(slamfe_dev_geom g, const uint8_t
         const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
         const int cx = (int)SLAMFE_KEY_X(key), cy = (int)SLAMFE_KEY_Y(key);
         if (cx < 16 || cy < 16 || cx >= w - 17 || cy >= h - 16) continue; // reads must stay inside
-        const uint8_t* base = frame + g.lv[l].off + (size_t)(cy - 15) * pitch + (cx - 15);
+        const uint8_t* level = l == 0 ? l0.base + (size_t)f * l0.frame_stride : frame + g.lv[l].off;
+        const uint8_t* base = level + (size_t)(cy - 15) * pitch + (cx - 15);
         const uint4 x4 = orient_load(W, base, pitch, lane);
         int m10, m01;
         orient_moments(W, x4, m10, m01);
@@ -447,7 +449,7 @@ int slamfe_launch_export(hipStream_t s, const int32_t* kp_count, const slamfe_ke
 int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
                          int slot_base, int nslots, const uint32_t* kp_key, const uint32_t* kp_level,
                          const int32_t* kp_count, int32_t* kp_mom, slamfe_keypoint* kps, float* kp_rot,
-                         int max_kp, int mode, int patch_size)
+                         int max_kp, int mode, int patch_size, slamfe_level0 l0)
 {
     if (mode == SLAMFE_MODE_ORB) {
         // about four keypoints per wavefront when the level quotas are met exactly;
@@ -457,7 +459,7 @@ int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
         if (est < 64 || est > max_kp) est = max_kp;
         hipLaunchKernelGGL(k_orient, frame_grid((int)((est + 15) / 16), nframes), dim3(256), 0, s, g, pyr,
                            slot_base, nslots, kp_key, kp_level, kp_count,
-                           reinterpret_cast<int2*>(kp_mom), max_kp, nframes);
+                           reinterpret_cast<int2*>(kp_mom), max_kp, nframes, l0);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_finish, frame_grid((max_kp + 255) / 256, nframes), dim3(256), 0, s, g,

@@ -137,7 +137,7 @@ __device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
 
 __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nframes,
                                                 uint8_t* __restrict__ pyr,
-                                                const uint32_t* __restrict__ taps)
+                                                const uint32_t* __restrict__ taps, slamfe_level0 l0)
 {
     const slamfe_dev_level& S = g.lv[l - 1];
     const slamfe_dev_level& D = g.lv[l];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
     // frame of this lane: group member j = lane / 16 of the group blockIdx.z
     const int f = (int)((blockIdx.z * 4 + (unsigned)(lane >> 4)) * gridDim.x + blockIdx.x);
     const int x = (item % nxb) * 64 + (lane & 15) * 4;
-    const uint8_t* src = pyr + (size_t)f * g.frame_bytes + S.off;
+    const uint8_t* src = l == 1 ? l0.base + (size_t)f * l0.frame_stride : pyr + (size_t)f * g.frame_bytes + S.off;
     uint8_t* dst = pyr + (size_t)f * g.frame_bytes + D.off;
     const int spitch = S.pitch, dpitch = D.pitch;
     if (f < nframes && x < D.w) {
@@ -541,7 +541,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
 __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
                                                    uint8_t* __restrict__ blur, int nframes, int thr,
                                                    int edge, uint32_t* __restrict__ cand,
-                                                   uint32_t* __restrict__ cand_cnt)
+                                                   uint32_t* __restrict__ cand_cnt, slamfe_level0 l0)
 {
     __shared__ uint32_t tile32[FL_H * FL_WD];
     __shared__ uint32_t sc32[(FS_N + 3) / 4];
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     const int tx = tl % L.tiles_x, ty0 = (tl / L.tiles_x) * SLAMFE_FB_TILES;
     const int x0 = tx * TW, y0 = ty0 * TH;
     const int nrows = min(GH, L.h - y0); // image rows of this group
-    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + L.off;
+    const uint8_t* img = l == 0 ? l0.base + (size_t)f * l0.frame_stride : pyr + (size_t)f * g.frame_bytes + L.off;
 
     if (tid < SLAMFE_FB_TILES) nlist[tid] = 0;
     if (tid == 0) npos = 0;
@@ -857,14 +857,14 @@ int slamfe_launch_ingest_scaled(hipStream_t s, const uint8_t* d_in, int stride, 
 }
 
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
-                          const uint32_t* taps)
+                          const uint32_t* taps, slamfe_level0 l0)
 {
     for (int l = 1; l < g.nlevels; ++l) {
         // items = strips of 4 * RS_ROWS rows x blocks of 64 columns; a workgroup
         // covers four frames of the grid's frame axis (see k_resize)
         dim3 grid = frame_grid((g.lv[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS) * ((g.lv[l].w + 63) / 64), nframes);
         grid.z = (grid.z + 3) / 4;
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, g, l, nframes, pyr, taps);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, g, l, nframes, pyr, taps, l0);
         LAUNCH_CHECK();
     }
     return 0;
@@ -888,10 +888,11 @@ int slamfe_image_init(void)
 }
 
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt)
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
+                            slamfe_level0 l0)
 {
     hipLaunchKernelGGL(k_fast_blur, frame_grid(g.total_groups, nframes), dim3(256), 0, s, g, pyr, blur,
-                       nframes, thr, edge, cand, cand_cnt);
+                       nframes, thr, edge, cand, cand_cnt, l0);
     LAUNCH_CHECK();
     return 0;
 }

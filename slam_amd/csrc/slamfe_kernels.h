@@ -15,15 +15,24 @@ int slamfe_launch_ingest(hipStream_t s, const uint8_t* d_in, int w, int h, int s
 int slamfe_launch_ingest_scaled(hipStream_t s, const uint8_t* d_in, int stride, const uint32_t* xt,
                                 const uint32_t* yt, int dw, int dh, uint8_t* gray, int gpitch,
                                 uint8_t* bgr_out, int bpitch);
+/* Level 0 of a batch may live outside the pyramid buffer (the caller's gray frames,
+ * used in place when their layout is that of level 0): frame f's level 0 starts at
+ * l0.base + f * l0.frame_stride, rows of lv[0].pitch bytes.  Inside the pyramid:
+ * base = pyr + lv[0].off, frame_stride = frame_bytes. */
+typedef struct slamfe_level0 {
+    const uint8_t* base;
+    size_t frame_stride;
+} slamfe_level0;
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
-                          const uint32_t* taps);
+                          const uint32_t* taps, slamfe_level0 l0);
 /* Ingest + all pyramid levels in one launch (a few frames per call); d_in = NULL:
  * level 0 is already in pyr.  Needs g.pt_x > 0. */
 int slamfe_launch_pyramid_fused(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* d_in,
                                 int stride, size_t frame_stride, int channels, uint8_t* pyr,
                                 const uint32_t* taps);
 int slamfe_launch_fast_blur(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
-                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt);
+                            uint8_t* blur, int thr, int edge, uint32_t* cand, uint32_t* cand_cnt,
+                            slamfe_level0 l0);
 int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint32_t* cand,
                          const uint32_t* cand_cnt, uint32_t* band_hist, uint32_t* band_off,
                          uint32_t* level_kept, int32_t* level_cutoff, int slot_base, int nslots,
@@ -32,7 +41,7 @@ int slamfe_launch_select(hipStream_t s, const slamfe_dev_geom& g, int nframes, c
 int slamfe_launch_orient(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* pyr,
                          int slot_base, int nslots, const uint32_t* kp_key, const uint32_t* kp_level,
                          const int32_t* kp_count, int32_t* kp_mom, slamfe_keypoint* kps, float* kp_rot,
-                         int max_kp, int mode, int patch_size);
+                         int max_kp, int mode, int patch_size, slamfe_level0 l0);
 int slamfe_launch_describe(hipStream_t s, const slamfe_dev_geom& g, int nframes, const uint8_t* blur,
                            int slot_base, int nslots, const uint32_t* kp_key,
                            const uint32_t* kp_level, const int32_t* kp_count, const float* kp_rot,
