@@ -238,9 +238,11 @@ int slamfe_match_shard_keys(slamfe_ctx* ctx, const void* d_query, int nq, const 
  * per-chunk partial results live in a fixed 4 MiB device array of the library
  * (one per GPU, held until the process ends) instead of a buffer that grows on
  * demand, and the call makes no hipMalloc / hipFree.  The job must satisfy
- * chunks(nt) * nq * 8 <= 4 MiB, where a chunk is 8128 train rows under the
- * matrix-core kernel and 128 to 512 rows under the popcount kernel (2000 queries
- * x 1,000,000 rows on the matrix cores need 1.9 MiB); beyond that it returns
+ * chunks(nt) * nq * 8 <= 4 MiB, where a chunk is about 4096 train rows under
+ * the matrix-core kernel (2048 to 4096: the number of chunks is rounded so that
+ * the workgroups fill the chip evenly) and 128 to 512 rows under the popcount
+ * kernel (2000 queries x 1,000,000 rows on the matrix cores need 3.9 MiB, about
+ * the most that fits); beyond that it returns
  * SLAMFE_E_CAPACITY and launches nothing.  All contexts on one GPU share the
  * array: two such calls that overlap on one GPU (different streams) race.
  * Asynchronous on the context's stream. */

@@ -219,6 +219,33 @@ __device__ __forceinline__ uint32_t bits4_to_bytes128(uint32_t x, int pos)
     return (((x >> pos) & 0xFu) * 0x10204080u) & 0x80808080u;
 }
 
+#ifdef SLAMFE_STAMPS
+// Diagnostic build only: shader-clock and wall-clock stamps of wave 0 of 64 sampled
+// workgroups of k_match_mfma (kernel entry, stage loop entry and exit, kernel
+// exit; then the stage count), read back with slamfe_debug_match_stamps().
+__device__ unsigned long long g_mm_stamps[64 * 16];
+#define MM_STAMP(i)                                                                              \
+    do {                                                                                         \
+        if ((blockIdx.x & 31u) == 7u && (blockIdx.x >> 5) < 64u && threadIdx.x == 0) {            \
+            g_mm_stamps[(blockIdx.x >> 5) * 16 + 2 * (i)] = __builtin_amdgcn_s_memtime();        \
+            g_mm_stamps[(blockIdx.x >> 5) * 16 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                        \
+    } while (0)
+extern "C" int slamfe_debug_match_stamps(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_stamps), (size_t)n * 8);
+}
+// ... and of every workgroup (up to 4096): wall-clock entry and exit, the
+// hardware id register and the XCC id (where it ran)
+__device__ unsigned long long g_mm_where[4096 * 4];
+extern "C" int slamfe_debug_match_where(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_where), (size_t)n * 8);
+}
+#else
+#define MM_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_match_mfma(const uint32_t* __restrict__ query, int nq_imm,
                                                     const int32_t* __restrict__ nq_dev,
                                                     const uint32_t* __restrict__ train, int nt_imm,
@@ -227,6 +254,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                     slamfe_match_geo mg)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sA[3][MM_SUB][MM_TILE * MM_ROW];
+    MM_STAMP(0);
+#ifdef SLAMFE_STAMPS
+    if (blockIdx.x < 4096u && threadIdx.x == 0) {
+        g_mm_where[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        g_mm_where[blockIdx.x * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_mm_where[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     const int pair = (int)(blockIdx.x % (unsigned)mg.npairs);
     const int local = (int)(blockIdx.x / (unsigned)mg.npairs);
     if (ps.nslots) {
@@ -292,10 +327,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // a stage = MM_SUB tiles; the thread's piece of tile u of a stage: dword
     // (tid & 7) of row (tid >> 3)
     auto load_bits = [&](int st, int u) -> uint32_t {
-        // (no branch: the row is clamped and the value discarded past the chunk)
+        // (no branch and no select: past the chunk the row is clamped, and what the
+        // chains make of such a row is never looked at -- the top-2 update masks the
+        // rows beyond a short last tile and a missing tile is not computed.  The value
+        // is first used a stage later, so nothing in this stage waits for the load.)
         const int row = j0 + (st * MM_SUB + u) * MM_TILE + (tid >> 3);
-        const uint32_t v = train[(size_t)min(row, j1 - 1) * 8 + (tid & 7)];
-        return row < j1 ? v : 0u;
+        return train[(size_t)min(row, j1 - 1) * 8 + (tid & 7)];
     };
     auto store_tile = [&](int buf, int u, uint32_t bits) {
         const uint2 e0 = lut[bits & 0xffu], e1 = lut[(bits >> 8) & 0xffu];
@@ -385,6 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the compiler interleaves.  The last stage handles a short or missing tile.
     mm_v4i F[8], G[8];
     int cur = 0; // buffer of the stage being computed
+    MM_STAMP(1);
     for (int st = 0; st + 1 < nstages; ++st) {
         const int nxt = cur == 2 ? 0 : cur + 1;
         fetch(cur, 0, F);
@@ -426,6 +464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
 
+    MM_STAMP(2);
     // the two lane halves hold disjoint train rows of the same query: merge, then
     // make distance and row absolute
     const uint32_t last = (uint32_t)(ntiles - 1) * MM_TILE;
@@ -446,6 +485,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 make_uint2(conv(m1), conv(m2));
         }
     }
+    MM_STAMP(3);
+#ifdef SLAMFE_STAMPS
+    if ((blockIdx.x & 31u) == 7u && (blockIdx.x >> 5) < 64u && threadIdx.x == 0)
+        g_mm_stamps[(blockIdx.x >> 5) * 16 + 8] = (unsigned long long)nstages;
+    if (blockIdx.x < 4096u && threadIdx.x == 0) g_mm_where[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 __device__ __forceinline__ void top2_push(uint32_t k, uint32_t& b1, uint32_t& b2)
@@ -576,18 +621,31 @@ int slamfe_match_plan(int nq_max, int nt_max, int npairs, int kernel, int* qpt, 
     if (kernel == SLAMFE_MATCH_MATRIX || (kernel == SLAMFE_MATCH_AUTO && nq_max >= 128)) {
         // matrix-core kernel: a workgroup expands its 256 queries once (about the
         // cost of three tiles) and its stages hand over through a barrier, so chunks
-        // are long: up to what the key format allows (8128 rows) for large train
-        // sets, 4096 for frame pairs; shorter only when that would leave fewer than
-        // ~512 workgroups (a single frame pair).  Measured on MI355X: 2000 x 1M
-        // 4.79 / 4.86 / 5.01 T cmp/s with 2048 / 4096 / 8128 rows; 256 frame pairs
-        // 0.230 / 0.197 / 0.179 / 0.177 ms with 512 / 1024 / 2048 / 4096 rows.
+        // are long: 4096 rows for frame pairs, shorter only when that would leave
+        // fewer than ~512 workgroups (a single frame pair).  Measured on MI355X:
+        // 256 frame pairs 0.230 / 0.197 / 0.179 / 0.177 ms with 512 / 1024 / 2048 /
+        // 4096 rows.
+        // A large train set is cut into about 4096-row chunks, their number chosen so
+        // that the workgroups fill whole rounds of the chip's 512 places (two
+        // workgroups per CU): 2000 x 1M ran 6.13 T cmp/s with 8128-row chunks (992
+        // workgroups: the last round is a third empty, and the two workgroups of a CU
+        // do not run at the same speed), 6.33-6.39 with 3904-3936 rows (4 rounds),
+        // 5.9 with 992 rows (the query expansion weighs more).
         q = 64;
-        static const int lengths[] = {8128, 4096, 2048, 1024, 512, 256};
-        rows = 256;
-        for (int r : lengths) {
-            if (r > 4096 && nt_max <= 8192) continue;
-            rows = r;
-            if (have * ((nt_max + r - 1) / r) >= 512) break;
+        if (nt_max > 8192) {
+            const long long places = 512;
+            const long long rounds = (have * ((nt_max + 4095) / 4096) + places - 1) / places;
+            long long nc_want = rounds * places / have;
+            if (nc_want < 1) nc_want = 1;
+            long long r = ((nt_max + nc_want - 1) / nc_want + 31) / 32 * 32;
+            rows = (int)(r < 256 ? 256 : (r > 8128 ? 8128 : r));
+        } else {
+            static const int lengths[] = {4096, 2048, 1024, 512, 256};
+            rows = 256;
+            for (int r : lengths) {
+                rows = r;
+                if (have * ((nt_max + r - 1) / r) >= 512) break;
+            }
         }
     } else {
         // few queries: the VALU kernel, one query row per lane.  Measured on MI355X:

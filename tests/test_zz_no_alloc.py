@@ -27,7 +27,7 @@ def test_static_scratch_keys_equal_growable_buffer_keys(kernel):
     from slam_amd.frontend import FrontEnd, SlamfeError
     # first a large job (many chunks: the wave-per-query merge), then a smaller one
     # whose partials cover only the front of the array
-    # (the popcount kernel cuts the train set into chunks of 256 rows, not 8128: its
+    # (the popcount kernel cuts the train set into chunks of 256 rows, not thousands: its
     # large job is smaller so that the partials still fit the 4 MiB array)
     big = 60_000 if kernel == abi.MATCH_POPCOUNT else 300_000
     jobs = [(2000, big, 1_000_000), (300, 5000, 17), (129, 33, 0), (40, 3000, 5)]

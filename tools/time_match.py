@@ -22,10 +22,10 @@ torch.cuda.synchronize()
 for name, kern in (("matrix", abi.MATCH_MATRIX), ("popcount", abi.MATCH_POPCOUNT)):
     with FrontEnd(mode=abi.MODE_ORB, max_width=64, max_height=64, max_batch=1, map_capacity=0,
                   match_kernel=kern) as fe:
-        for _ in range(3):
+        for _ in range(int(os.environ.get('WARM', 100))):
             fe.match_shard_keys(q.data_ptr(), NQ, t.data_ptr(), NT, 0, keys.data_ptr())
         fe.sync()
-        R = 20
+        R = int(os.environ.get('REPS', 100))
         t0 = time.perf_counter()
         for _ in range(R):
             fe.match_shard_keys(q.data_ptr(), NQ, t.data_ptr(), NT, 0, keys.data_ptr())
