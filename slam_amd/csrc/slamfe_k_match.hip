@@ -154,50 +154,55 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 }
 
 // ---------------------------------------------------------------------------
-// K8m  the same brute-force Hamming k=2 on the matrix cores.
+// K8m  the same brute-force Hamming k=2 on the matrix cores, in FP4.
 //
 // With train bits a in {0, 1} and query bits mapped to b' = 1 - 2b in {+1, -1},
 //   sum_k a_k * b'_k = popcount(a) - 2 a.b = hamming(a, b) - popcount(b),
-// so one v_mfma_i32_32x32x32_i8 chain over the 256 bit positions (8 MFMAs) gives
-// the exact distances of 32 train rows x 32 queries, minus a per-query constant
-// that does not change the order.  The operands are stored scaled, train bits as
-// {0, -128} and query bits b as {-64, +64} (the product of a set train bit with b'
-// is then 8192 b'), so the chain delivers the distance times 8192 = shifted left
-// by 13, and the chain's initial accumulator holds (256 << 13) + bias +
-// row-in-tile per result register: the MFMA result IS the key (distance << 13 |
-// row), no instruction builds it.  In the result tile the
-// query is the lane (column) and the 16 registers are train rows, so the running
-// top-2 of a query stays in its lane: v_min / v_med3 per key as in the VALU
-// kernel, 2 VALU operations per comparison instead of 19; the 8 MFMAs of a tile
-// take 256 cycles per SIMD.
+// so a chain of matrix instructions over the 256 bit positions gives the exact
+// distances of 32 train rows x 32 queries, minus a per-query constant that does
+// not change the order.  gfx950's v_mfma_f32_32x32x64_f8f6f4 takes 4-bit floats
+// (E2M1: 0, 0.5 .. 6) and covers 64 bit positions per instruction in the time the
+// 8-bit integer instruction covers 32: a bit is a nibble, train bits are stored as
+// {0, +4} and query bits as {+4, -4}, so the chain (4 instructions) delivers
+// 16 * (distance - popcount(b)) in f32, exactly (every partial sum is a multiple
+// of 16 below 2^14).
 //
-// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to -+64 bytes in
-// 64 VGPRs per lane) x one chunk of train rows.  Train rows are read packed
-// (32 bytes), expanded to 0 / 0x80 bytes into LDS (one dword -> 32 bytes per thread
-// and tile, rows padded to 272 bytes so that the 16-byte fragment reads are
-// conflict-free), in three buffers of one stage (two tiles) each.  A stage is one block
-// of straight-line code: the 16 fragment reads of both tiles are issued first,
-// then the chains of tile t run while the vector ALU updates the top-2 from tile
-// t-1 (two accumulator sets) and expands the next stage's rows; 2 waves per SIMD
-// (242 VGPRs).  Row indices inside the keys are relative to the current tile
-// (older entries are moved down by 32 per tile: 2 operations per tile instead of
-// re-basing 16 constants) and made absolute at the end.
+// The chain's initial accumulator holds 16 * 256 + (bias + row in tile) / 1024
+// per result register, so the result IS the key: distance in the integer part,
+// row in the fraction (23 significant bits, all exact in f32).  Keys are positive
+// floats, whose order is the order of their bit patterns: the running top-2 is
+// kept with the integer v_min_u32 / v_med3_u32 on the raw registers.  In the
+// result tile the query is the lane (column) and the 16 registers are train rows,
+// so the top-2 of a query stays in its lane: 2 vector operations per comparison
+// instead of 19.  Row numbers inside the keys are relative to the current tile
+// (older entries are moved down by 32 rows = 1/32 per tile, one v_sub_f32 each,
+// instead of re-basing 16 constants) and made absolute at the end.
 //
-// Measured on MI355X (tools/ubench_mfma.hip, tools/time_match.py): the bare MFMA
-// chain with these operands runs at 4.9 POP/s (32.8 cycles per MFMA), and two
-// chains with 8 independent vector operations per MFMA still at 39 cycles, so
-// issue port and matrix pipe do overlap; the kernel (about 6 vector operations
-// per MFMA after the key and lookup-table changes) takes 0.43 ms for 2000 x 1M
-// where the chains alone take 0.28: what remains is the hand-over between
-// stages (fragment reads after the barrier, expansion stores before it).
+// A workgroup = 256 queries (4 waves x 2 blocks of 32, expanded to nibbles in 32
+// VGPRs per lane) x one chunk of train rows.  Train rows are read packed (32
+// bytes), expanded to nibbles in LDS (one dword -> 16 bytes per thread and tile
+// through a 256-entry byte -> 8 nibbles table, rows padded to 144 bytes so that
+// the 16-byte fragment reads are conflict-free), in three buffers of one stage
+// (two tiles) each.  A stage is one block of straight-line code: the fragment
+// reads of both tiles are issued first, then the chains of tile t run while the
+// vector ALU updates the top-2 from tile t-1 (two accumulator sets) and expands
+// the next stage's rows.
+//
+// Measured on MI355X (tools/ubench_mfma_fp4.hip, tools/time_match.py,
+// tools/match_stamps.py): the bare chain runs at 8.1 P bit-operations/s, and with
+// the vector work of the top-2 update beside it (about 10 operations per matrix
+// instruction) at 5.4: this kernel is bound by vector issue, not by the matrix
+// pipe.  The 8-bit integer form it replaces (8 instructions per chain, 4.9 P
+// bare) was bound by the matrix pipe and ran 2000 x 1M in 0.31 ms.
 // ---------------------------------------------------------------------------
 #define MM_TILE 32
 #define MM_SUB 2 /* tiles per LDS stage (one workgroup barrier per stage) */
-#define MM_ROW 272
+#define MM_ROW 144
 #define MM_BIAS 8128u /* >= 32 * (tiles per chunk - 1), < 8192 - 31: chunks of at most 8160 rows */
-#define MM_SHIFT 13
+#define MM_FRAC 1024.0f /* key = 16 * (distance + 256 - popcount(query)) + (MM_BIAS + row) / MM_FRAC */
+#define MM_NONE 0x7f800000u /* +inf: "no key"; stays +inf under the per-tile subtraction */
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
-typedef int mm_v16i __attribute__((ext_vector_type(16)));
+typedef float mm_v16f __attribute__((ext_vector_type(16)));
 
 // Median of three, which the compiler turns into one v_med3_u32.  (Not inline
 // assembly: the compiler's hazard handling does not see a read of an MFMA result
@@ -208,15 +213,12 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     return max(min(a, b), min(max(a, b), c));
 }
 
-// bits pos .. pos+3 of x -> four bytes of 0 / 1 (bit i in byte i)
-__device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x, int pos)
+// the 8 bits of a byte -> 8 nibbles of 0 / 1 (bit i in nibble i)
+__device__ __forceinline__ uint32_t bits8_to_nibbles(uint32_t x)
 {
-    return (((x >> pos) & 0xFu) * 0x00204081u) & 0x01010101u;
-}
-// the same with 0x80 (-128 as int8) for a set bit
-__device__ __forceinline__ uint32_t bits4_to_bytes128(uint32_t x, int pos)
-{
-    return (((x >> pos) & 0xFu) * 0x10204080u) & 0x80808080u;
+    uint32_t t = (x | (x << 12)) & 0x000f000fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    return (t | (t << 3)) & 0x11111111u;
 }
 
 #ifdef SLAMFE_STAMPS
@@ -294,15 +296,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
 
-    // byte -> eight 0 / 0x80 bytes: the expansion of the train rows is a table lookup
-    // (4 LDS reads per dword instead of 24 vector operations; the kernel's time is
-    // its vector issue slots as much as its matrix pipe)
-    __shared__ uint2 lut[256];
-    lut[tid] = make_uint2(bits4_to_bytes128((uint32_t)tid, 0), bits4_to_bytes128((uint32_t)tid, 4));
+    // byte -> eight nibbles of 0 / 6 (FP4 +4.0): the expansion of the train rows is a
+    // table lookup (4 LDS reads per dword instead of two dozen vector operations)
+    __shared__ uint32_t lut[256];
+    lut[tid] = bits8_to_nibbles((uint32_t)tid) * 6u;
 
-    // query fragments: lane (r, h) holds bits 16h .. 16h+15 of every dword of its
-    // query row as +-1 bytes
-    mm_v4i B[2][8];
+    // query fragments: the instruction's 64 bit positions are two dwords of the
+    // row, one per lane half; lane (r, h) holds dword 2 kb + h of its query row
+    // as 32 nibbles of 6 (+4.0, bit clear) / 0xe (-4.0, bit set).  (Which bit sits
+    // in which nibble does not matter as long as train rows use the same map.)
+    mm_v4i B[2][4];
     int pq[2];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -312,14 +315,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const uint32_t qw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         int pc = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            pc += __popc(qw[kb]);
-            const uint32_t half = (qw[kb] >> (16 * h)) & 0xffffu;
+        for (int w = 0; w < 8; ++w) pc += __popc(qw[w]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const uint32_t t = bits4_to_bytes(half, 4 * n);
-                B[blk][kb][n] = (int)((~((t << 8) - t) & 0x80808080u) | 0x40404040u); // bit 1 -> 0x40 (+64), bit 0 -> 0xc0 (-64)
-            }
+        for (int kb = 0; kb < 4; ++kb) {
+            const uint32_t mine = h ? qw[2 * kb + 1] : qw[2 * kb];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                B[blk][kb][n] = (int)(0x66666666u | (bits8_to_nibbles((mine >> (8 * n)) & 0xffu) << 3));
         }
         pq[blk] = pc;
     }
@@ -335,12 +337,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return train[(size_t)min(row, j1 - 1) * 8 + (tid & 7)];
     };
     auto store_tile = [&](int buf, int u, uint32_t bits) {
-        const uint2 e0 = lut[bits & 0xffu], e1 = lut[(bits >> 8) & 0xffu];
-        const uint2 e2 = lut[(bits >> 16) & 0xffu], e3 = lut[bits >> 24];
-        const uint4 a = make_uint4(e0.x, e0.y, e1.x, e1.y), b = make_uint4(e2.x, e2.y, e3.x, e3.y);
-        uint4* d = reinterpret_cast<uint4*>(&sA[buf][u][(tid >> 3) * MM_ROW + (tid & 7) * 32]);
-        d[0] = a;
-        d[1] = b;
+        const uint4 e = make_uint4(lut[bits & 0xffu], lut[(bits >> 8) & 0xffu], lut[(bits >> 16) & 0xffu],
+                                   lut[bits >> 24]);
+        *reinterpret_cast<uint4*>(&sA[buf][u][(tid >> 3) * MM_ROW + (tid & 7) * 16]) = e;
     };
     const int ntiles = (j1 - j0 + MM_TILE - 1) / MM_TILE;
     const int nstages = (ntiles + MM_SUB - 1) / MM_SUB;
@@ -356,41 +355,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
 
     // result register j of lane half h is train row (j & 3) + 8 (j >> 2) + 4 h of the tile
-    // and the accumulators start from (256 << MM_SHIFT) + MM_BIAS + that row, so
-    // that the MFMA chain delivers the finished keys
-    mm_v16i cj;
+    // and the accumulators start from 16 * 256 + (MM_BIAS + that row) / MM_FRAC, so
+    // that the chain delivers the finished keys
+    mm_v16f cj;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) cj[j] = (int)((256u << MM_SHIFT) + MM_BIAS + (uint32_t)((j & 3) + 8 * (j >> 2) + 4 * h));
-    uint32_t b1[2] = {0xffffffffu, 0xffffffffu}, b2[2] = {0xffffffffu, 0xffffffffu};
+    for (int j = 0; j < 16; ++j)
+        cj[j] = 4096.0f + (float)(MM_BIAS + (uint32_t)((j & 3) + 8 * (j >> 2) + 4 * h)) * (1.0f / MM_FRAC);
+    uint32_t b1[2] = {MM_NONE, MM_NONE}, b2[2] = {MM_NONE, MM_NONE};
 
-    // One tile's fragment reads (8 x 16 bytes per lane) and MFMA chains (two query
+    // One tile's fragment reads (4 x 16 bytes per lane) and chains (two query
     // blocks).  The reads of a tile are issued a whole tile ahead of the chains
     // that consume them, so their LDS latency hides under the previous chains.
     auto fetch = [&](int buf, int u, mm_v4i* a) {
         const uint8_t* base = &sA[buf][u][r * MM_ROW + h * 16];
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) a[kb] = *reinterpret_cast<const mm_v4i*>(base + kb * 32);
+        for (int kb = 0; kb < 4; ++kb) a[kb] = *reinterpret_cast<const mm_v4i*>(base + kb * 32);
     };
-    auto compute = [&](const mm_v4i* a, mm_v16i& acc0, mm_v16i& acc1) {
+    // (FP4 operands are 4 registers; the builtin's type has 8, the upper 4 are not read)
+#define MM_WIDE(x) __builtin_shufflevector(x, x, 0, 1, 2, 3, -1, -1, -1, -1)
+    auto compute = [&](const mm_v4i* a, mm_v16f& acc0, mm_v16f& acc1) {
         acc0 = cj;
         acc1 = cj;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], B[0][kb], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], B[1][kb], acc1, 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb) {
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(MM_WIDE(a[kb]), MM_WIDE(B[0][kb]), acc0, 4, 4, 0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(MM_WIDE(a[kb]), MM_WIDE(B[1][kb]), acc1, 4, 4, 0, 0, 0, 0);
         }
     };
     // ... and the top-2 update from a finished tile's keys.  The two are issued
     // for different tiles: the update of tile t runs on the vector ALU while the
     // matrix core works on tile t+1 (two accumulator sets).
-    auto extract = [&](const mm_v16i& acc0, const mm_v16i& acc1, int rows) {
+    auto down = [](uint32_t k) { return __float_as_uint(__uint_as_float(k) - (float)MM_TILE * (1.0f / MM_FRAC)); };
+    auto extract = [&](const mm_v16f& acc0, const mm_v16f& acc1, int rows) {
         // entries of earlier tiles move down by one tile
-        b1[0] -= MM_TILE; b2[0] -= MM_TILE; b1[1] -= MM_TILE; b2[1] -= MM_TILE;
+        b1[0] = down(b1[0]); b2[0] = down(b2[0]); b1[1] = down(b1[1]); b2[1] = down(b2[1]);
         if (rows >= MM_TILE) { // uniform; only the last tile of a chunk can be short
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                uint32_t k0 = (uint32_t)acc0[j];
-                uint32_t k1 = (uint32_t)acc1[j];
+                uint32_t k0 = __float_as_uint(acc0[j]);
+                uint32_t k1 = __float_as_uint(acc1[j]);
                 uint32_t n0, n1;
                 n0 = umed3(k0, b1[0], b2[0]);
                 n1 = umed3(k1, b1[1], b2[1]);
@@ -401,8 +404,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const bool ok = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
-                uint32_t k0 = ok ? (uint32_t)acc0[j] : 0xffffffffu;
-                uint32_t k1 = ok ? (uint32_t)acc1[j] : 0xffffffffu;
+                uint32_t k0 = ok ? __float_as_uint(acc0[j]) : MM_NONE;
+                uint32_t k1 = ok ? __float_as_uint(acc1[j]) : MM_NONE;
                 uint32_t n0, n1;
                 n0 = umed3(k0, b1[0], b2[0]);
                 n1 = umed3(k1, b1[1], b2[1]);
@@ -413,14 +416,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     static_assert(MM_SUB == 2, "the stage loop below is written for two tiles per stage");
     const int last_rows = j1 - (j0 + (ntiles - 1) * MM_TILE); // valid rows of the last tile
-    mm_v16i P0, P1, Q0, Q1; // even tiles accumulate in P, odd tiles in Q
+    mm_v16f P0, P1, Q0, Q1; // even tiles accumulate in P, odd tiles in Q
 #pragma unroll
-    for (int j = 0; j < 16; ++j) Q0[j] = Q1[j] = -1;
+    for (int j = 0; j < 16; ++j) Q0[j] = Q1[j] = __uint_as_float(MM_NONE);
     // All stages but the last are straight-line code (both tiles full, a next stage
     // to load): fragment reads, the two tiles' chains, the updates of the tiles
     // before them and the expansion of the next stage's rows share one block that
     // the compiler interleaves.  The last stage handles a short or missing tile.
-    mm_v4i F[8], G[8];
+    mm_v4i F[4], G[4];
     int cur = 0; // buffer of the stage being computed
     MM_STAMP(1);
     for (int st = 0; st + 1 < nstages; ++st) {
@@ -476,9 +479,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int qi = qfirst + 32 * blk;
         if (h == 0 && qi < nq) {
             auto conv = [&](uint32_t k) -> uint32_t {
-                if (k >= 0xC0000000u) return SLAMFE_MKEY_NONE;
-                const uint32_t d = (k >> MM_SHIFT) - 256u + (uint32_t)pq[blk];
-                const uint32_t row = (k & ((1u << MM_SHIFT) - 1u)) - MM_BIAS + last + (uint32_t)j0;
+                if (k >= MM_NONE) return SLAMFE_MKEY_NONE;
+                // key * MM_FRAC is an integer below 2^24: (distance + 256 - popcount) << 14 | bias + row
+                const uint32_t ki = (uint32_t)(__uint_as_float(k) * MM_FRAC);
+                const uint32_t d = (ki >> 14) - 256u + (uint32_t)pq[blk];
+                const uint32_t row = (ki & 16383u) - MM_BIAS + last + (uint32_t)j0;
                 return (d << SLAMFE_MKEY_SHIFT) | row;
             };
             reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
