@@ -49,7 +49,12 @@ W, H, NFEAT, THR = 640, 480, 2000, 20
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TOPS = 41.0  # measured: tools/ubench_valu.hip, v_xor + accumulating v_bcnt
 VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, one per 4 cycles, 2.4 GHz
-MFMA_I8_PEAK_TOPS = 2048 * 1024 * 2.4e9 / 1e12  # dense int8 MFMA peak, 5033 TOP/s
+MFMA_FP4_PEAK_TOPS = 4096 * 1024 * 2.4e9 / 1e12  # dense FP4 MFMA peak (twice int8 / fp8), 10066 TOP/s
+# k_match_mfma, per 32 x 32 tile of comparisons and wave: 4 matrix instructions (each
+# holds the SIMD's vector issue for 8 cycles = 2 slots) and 28 vector instructions (20
+# of the top-2 update, 8 of key shifting, row expansion and addressing: 112 per stage
+# of four tiles, counted in the compiled stage loop)
+MATCH_ISSUE_SLOTS_PER_TILE = 4 * 2 + 28
 
 STAGES = {"pyramid": 1, "fast_blur": 2, "select": 3, "orient": 4, "describe": 6, "match": 7}
 MATCH_FIELDS = ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound")
@@ -620,14 +625,21 @@ def main():
     cmps = float((all_counts[:-1] * all_counts[1:]).sum() + all_counts[0] * all_counts[-1])
     gc = cmps / (stage_ms["match"] * 1e-3) / 1e9
     # The match kernel runs on the matrix cores: one 256-bit comparison = 256
-    # int8 multiply-accumulates = 512 operations of v_mfma_i32_32x32x32_i8, whose
-    # dense peak is 2048 op/clk/SIMD x 1024 SIMDs x 2.4 GHz.  (The integer-VALU
-    # formulation, 16 lane-ops per comparison, tops out at 41.0 T lane-ops/s =
-    # 2.56 T cmp/s: measured by tools/ubench_valu.hip.)
-    hamming = {"frame_pairs_gcmps": round(gc, 2),
-               "mfma_roofline": {"bound": "mfma", "ops_per_cmp": 512,
-                                 "achieved": round(gc * 512 / 1e3, 1), "peak": MFMA_I8_PEAK_TOPS,
-                                 "unit": "TOP/s", "frac": round(gc * 512 / 1e3 / MFMA_I8_PEAK_TOPS, 4)},
+    # FP4 multiply-accumulates = 512 operations of v_mfma_f32_32x32x64_f8f6f4, whose
+    # dense peak is 4096 op/clk/SIMD x 1024 SIMDs x 2.4 GHz.  At that instruction's
+    # rate the kernel is bound by vector issue (the top-2 update, 2 operations per
+    # comparison and lane), which "vector_issue" prices: issue slots of 4 cycles per
+    # SIMD.  (The integer-VALU formulation, 16 lane-ops per comparison, tops out at
+    # 41.0 T lane-ops/s = 2.56 T cmp/s: measured by tools/ubench_valu.hip.)
+    def match_roofline(gcmps, gpus=1):
+        return {"bound": "mfma", "operands": "fp4 (E2M1), f32 accumulate", "ops_per_cmp": 512,
+                "achieved": round(gcmps * 512 / 1e3, 1), "peak": MFMA_FP4_PEAK_TOPS * gpus, "unit": "TOP/s",
+                "frac": round(gcmps * 512 / 1e3 / (MFMA_FP4_PEAK_TOPS * gpus), 4),
+                "vector_issue": {"slots_per_1024_cmps": MATCH_ISSUE_SLOTS_PER_TILE,
+                                 "frac": round(gcmps * 1e9 / 1024 * MATCH_ISSUE_SLOTS_PER_TILE
+                                               / (VALU_ISSUE_PER_S * gpus), 4)}}
+
+    hamming = {"frame_pairs_gcmps": round(gc, 2), "mfma_roofline": match_roofline(gc),
                "valu_formulation_ceiling_gcmps": round(VALU_PEAK_TOPS * 1e3 / 16, 1)}
 
     # relocalisation: 2000 queries against a 1M-row map sharded over the ranks
@@ -651,14 +663,14 @@ def main():
                     fe.merge_shard_keys(keys.data_ptr(), 1, NQ, out.data_ptr())
 
             with torch.cuda.stream(stream):
-                for _ in range(3):
+                for _ in range(50):  # (the chip takes some tens of launches to reach its clock)
                     reloc()
                 torch.cuda.synchronize(dev)
                 if multi:
                     dist.barrier()
                 torch.cuda.synchronize(dev)
                 r0 = time.perf_counter()
-                R = 20
+                R = 50
                 for _ in range(R):
                     reloc()
                 torch.cuda.synchronize(dev)
@@ -721,7 +733,7 @@ def main():
                 hamming["popcount_kernel_valu_roofline"] = {
                     "bound": "integer VALU", "lane_ops_per_cmp": 16, "achieved_Tops": round(pc * 16 / 1e3, 2),
                     "peak_Tops": VALU_PEAK_TOPS, "frac": round(pc * 16 / 1e3 / VALU_PEAK_TOPS, 4)}
-            hamming["reloc_mfma_frac"] = round(NQ * NT * R / rel / 1e12 * 512 / (MFMA_I8_PEAK_TOPS * world), 4)
+            hamming["reloc_mfma_roofline"] = match_roofline(NQ * NT * R / rel / 1e9, world)
             hamming["reloc_ms_per_query_set"] = round(rel / R * 1e3, 4)
             hamming["reloc_scaling"] = "strong (map rows split over ranks, RCCL all-gather of top-2 keys)"
             del shard

@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
 // floats, whose order is the order of their bit patterns: the running top-2 is
 // kept with the integer v_min_u32 / v_med3_u32 on the raw registers.  In the
 // result tile the query is the lane (column) and the 16 registers are train rows,
-// so the top-2 of a query stays in its lane: 2 vector operations per comparison
-// instead of 19.  Row numbers inside the keys are relative to the current tile
+// so the top-2 of a query stays in its lane: 1.5 vector operations per comparison
+// (v_min3, v_med3, v_min per two keys) instead of 19.  Row numbers inside the keys are relative to the current tile
 // (older entries are moved down by 32 rows = 1/32 per tile, one v_sub_f32 each,
 // instead of re-basing 16 constants) and made absolute at the end.
 //
@@ -389,28 +389,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto extract = [&](const mm_v16f& acc0, const mm_v16f& acc1, int rows) {
         // entries of earlier tiles move down by one tile
         b1[0] = down(b1[0]); b2[0] = down(b2[0]); b1[1] = down(b1[1]); b2[1] = down(b2[1]);
+        // Two keys x, y at a time: with b1 <= b2 the second smallest of (x, y, b1, b2)
+        // is min(med3(x, y, b1), b2) and the smallest min3(x, y, b1): 3 operations
+        // per pair of comparisons.
+        // (min3 is associated differently from the min(x, y) inside the median so that
+        // the two do not share a subexpression: sharing it keeps the compiler from
+        // forming v_med3 and v_min3.)
+        auto push2 = [](uint32_t x, uint32_t y, uint32_t& lo, uint32_t& hi) {
+            const uint32_t m = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(x), __uint_as_float(y), __uint_as_float(lo)));
+            lo = min(x, min(y, lo));
+            hi = min(m, hi);
+        };
         if (rows >= MM_TILE) { // uniform; only the last tile of a chunk can be short
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t k0 = __float_as_uint(acc0[j]);
-                uint32_t k1 = __float_as_uint(acc1[j]);
-                uint32_t n0, n1;
-                n0 = umed3(k0, b1[0], b2[0]);
-                n1 = umed3(k1, b1[1], b2[1]);
-                b1[0] = min(k0, b1[0]); b2[0] = n0;
-                b1[1] = min(k1, b1[1]); b2[1] = n1;
+            for (int j = 0; j < 16; j += 2) {
+                push2(__float_as_uint(acc0[j]), __float_as_uint(acc0[j + 1]), b1[0], b2[0]);
+                push2(__float_as_uint(acc1[j]), __float_as_uint(acc1[j + 1]), b1[1], b2[1]);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool ok = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
-                uint32_t k0 = ok ? __float_as_uint(acc0[j]) : MM_NONE;
-                uint32_t k1 = ok ? __float_as_uint(acc1[j]) : MM_NONE;
-                uint32_t n0, n1;
-                n0 = umed3(k0, b1[0], b2[0]);
-                n1 = umed3(k1, b1[1], b2[1]);
-                b1[0] = min(k0, b1[0]); b2[0] = n0;
-                b1[1] = min(k1, b1[1]); b2[1] = n1;
+            for (int j = 0; j < 16; j += 2) {
+                const bool ok0 = (j & 3) + 8 * (j >> 2) + 4 * h < rows;
+                const bool ok1 = ((j + 1) & 3) + 8 * ((j + 1) >> 2) + 4 * h < rows;
+                push2(ok0 ? __float_as_uint(acc0[j]) : MM_NONE, ok1 ? __float_as_uint(acc0[j + 1]) : MM_NONE, b1[0], b2[0]);
+                push2(ok0 ? __float_as_uint(acc1[j]) : MM_NONE, ok1 ? __float_as_uint(acc1[j + 1]) : MM_NONE, b1[1], b2[1]);
             }
         }
     };
