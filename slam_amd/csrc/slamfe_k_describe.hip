@@ -266,9 +266,16 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
     // only this wavefront reads what it wrote: LDS operations of one wave are
     // ordered, the fences keep the compiler from moving accesses across
     wave_lds_fence();
+    typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
     const uint8_t* c = reinterpret_cast<const uint8_t*>(my) + (cy - 8 * R.ty0) * DP_PITCH + (cx - 16 * R.tx0);
     const desc_v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
+    // Adding 1.5 * 2^23 rounds to the nearest integer r (ties to even, as cvRound)
+    // and leaves the float's bit pattern at 0x4B400000 + r.  The sample's LDS address
+    // c + 64 * ry + rx is therefore (bits(y) << 6) + bits(x) plus a constant, in
+    // 32-bit modular arithmetic: one v_lshl_add and one v_add per sample.
     const desc_v2f magic = {12582912.f, 12582912.f};
+    static_assert(DP_PITCH == 64, "the sample address below shifts y by 6");
+    const uint32_t c0 = (uint32_t)(uintptr_t)(lds_bytes)c - 0x4B400000u * 65u;
     unsigned long long word[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -277,8 +284,8 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
         for (int e = 0; e < 2; ++e) {
             desc_v2f pt = D.P[j][e] * AB + D.Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
             pt = pt + magic;
-            const int ix = (short)__float_as_int(pt.x), iy = (short)__float_as_int(pt.y);
-            v[e] = c[iy * DP_PITCH + ix];
+            const uint32_t at = (__float_as_uint(pt.y) << 6) + __float_as_uint(pt.x) + c0;
+            v[e] = *(lds_bytes)(uintptr_t)at;
         }
         word[j] = __ballot(v[0] < v[1]);
     }
