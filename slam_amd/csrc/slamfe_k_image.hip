@@ -134,6 +134,7 @@ __device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
 // by both destination rows that blend it (consecutive destination rows share a
 // source row: 1.2 source rows per destination row instead of 2).
 #define RS_ROWS 4
+#define RS_PRE 7 /* source rows requested at once */
 
 __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nframes,
                                                 uint8_t* __restrict__ pyr,
@@ -186,52 +187,84 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
             }
             return make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
         };
-        // walk the source rows the strip needs in order; the next row's 12 bytes are
-        // requested before the current row is processed
+        // one destination row from the horizontal passes of its two source rows
+        auto emit = [&](const uint2& H0, const uint2& H1, uint32_t w1, int y) {
+            const slamfe_us2 wv2 = as_us2((256u - w1) | (w1 << 16));
+            // pair the two rows' values of each pixel: (h0, h1) -> one v_dot2 with the
+            // rounding constant as the addend: out = (h0*w0 + h1*w1 + 2^15) >> 16
+            const uint32_t e0 = __builtin_amdgcn_perm(H1.x, H0.x, 0x05040100u); // px0: low halves
+            const uint32_t e1 = __builtin_amdgcn_perm(H1.x, H0.x, 0x07060302u); // px1: high halves
+            const uint32_t e2 = __builtin_amdgcn_perm(H1.y, H0.y, 0x05040100u);
+            const uint32_t e3 = __builtin_amdgcn_perm(H1.y, H0.y, 0x07060302u);
+            // each sum is at most 65280 * 256 + 2^15 < 2^24: its byte 2 is the pixel
+            const uint32_t v0 = __builtin_amdgcn_udot2(as_us2(e0), wv2, 1u << 15, false);
+            const uint32_t v1 = __builtin_amdgcn_udot2(as_us2(e1), wv2, 1u << 15, false);
+            const uint32_t v2 = __builtin_amdgcn_udot2(as_us2(e2), wv2, 1u << 15, false);
+            const uint32_t v3 = __builtin_amdgcn_udot2(as_us2(e3), wv2, 1u << 15, false);
+            const uint32_t out = __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u) |
+                                 __builtin_amdgcn_perm(v3, v2, 0x06020c0cu);
+            // rows are padded to a multiple of 64 bytes: the dword store stays in the row
+            *reinterpret_cast<uint32_t*>(dst + (size_t)y * dpitch + x) = out;
+        };
+        // walk the source rows the strip needs in order
         int y = y_first;
         uint32_t ty = taps[D.tap_y + y];
         int yo = (int)(ty & 0xffffu);
         uint32_t w1 = ty >> 16;
         int yo1 = yo + (w1 ? 1 : 0);
         int sy = yo;
-        uint3 pw = *reinterpret_cast<const uint3*>(src + (size_t)sy * spitch + a);
-        uint32_t p0 = pw.x, p1 = pw.y, p2 = pw.z;
+        const uint32_t ty_last = taps[D.tap_y + y_end - 1];
+        const int sy_last = (int)(ty_last & 0xffffu) + ((ty_last >> 16) ? 1 : 0); // uniform
         uint2 Hprev = make_uint2(0, 0), Hcur = make_uint2(0, 0);
-        while (y < y_end) { // uniform
-            const int nsy = min(sy + 1, S.h - 1);
-            const uint3 nw = *reinterpret_cast<const uint3*>(src + (size_t)nsy * spitch + a);
-            const uint32_t n0 = nw.x, n1 = nw.y, n2 = nw.z;
-            Hprev = Hcur;
-            Hcur = hpass(p0, p1, p2);
-            while (y < y_end && yo1 == sy) { // destination rows whose second source row is sy
-                const uint2 H0 = yo == sy ? Hcur : Hprev;
-                const slamfe_us2 wv2 = as_us2((256u - w1) | (w1 << 16));
-                // pair the two rows' values of each pixel: (h0, h1) -> one v_dot2 with the
-                // rounding constant as the addend: out = (h0*w0 + h1*w1 + 2^15) >> 16
-                const uint32_t e0 = __builtin_amdgcn_perm(Hcur.x, H0.x, 0x05040100u); // px0: low halves
-                const uint32_t e1 = __builtin_amdgcn_perm(Hcur.x, H0.x, 0x07060302u); // px1: high halves
-                const uint32_t e2 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x05040100u);
-                const uint32_t e3 = __builtin_amdgcn_perm(Hcur.y, H0.y, 0x07060302u);
-                // each sum is at most 65280 * 256 + 2^15 < 2^24: its byte 2 is the pixel
-                const uint32_t v0 = __builtin_amdgcn_udot2(as_us2(e0), wv2, 1u << 15, false);
-                const uint32_t v1 = __builtin_amdgcn_udot2(as_us2(e1), wv2, 1u << 15, false);
-                const uint32_t v2 = __builtin_amdgcn_udot2(as_us2(e2), wv2, 1u << 15, false);
-                const uint32_t v3 = __builtin_amdgcn_udot2(as_us2(e3), wv2, 1u << 15, false);
-                const uint32_t out = __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u) |
-                                     __builtin_amdgcn_perm(v3, v2, 0x06020c0cu);
-                // rows are padded to a multiple of 64 bytes: the dword store stays in the row
-                *reinterpret_cast<uint32_t*>(dst + (size_t)y * dpitch + x) = out;
-                if (++y < y_end) {
-                    ty = taps[D.tap_y + y];
-                    yo = (int)(ty & 0xffffu);
-                    w1 = ty >> 16;
-                    yo1 = yo + (w1 ? 1 : 0);
+        if (sy_last - sy < RS_PRE) {
+            // (the usual case: RS_ROWS rows at scale 1.2 blend at most six source rows)
+            // all source rows are requested at once, so that the wave waits for memory
+            // once and not once per row
+            uint3 R[RS_PRE];
+#pragma unroll
+            for (int k = 0; k < RS_PRE; ++k)
+                R[k] = *reinterpret_cast<const uint3*>(src + (size_t)min(min(sy + k, sy_last), S.h - 1) * spitch + a);
+#pragma unroll
+            for (int k = 0; k < RS_PRE; ++k) {
+                if (y < y_end) { // uniform
+                    Hprev = Hcur;
+                    Hcur = hpass(R[k].x, R[k].y, R[k].z);
+                    while (y < y_end && yo1 == sy) { // destination rows whose second source row is sy
+                        emit(yo == sy ? Hcur : Hprev, Hcur, w1, y);
+                        if (++y < y_end) {
+                            ty = taps[D.tap_y + y];
+                            yo = (int)(ty & 0xffffu);
+                            w1 = ty >> 16;
+                            yo1 = yo + (w1 ? 1 : 0);
+                        }
+                    }
+                    ++sy;
                 }
             }
-            ++sy;
-            p0 = n0;
-            p1 = n1;
-            p2 = n2;
+        } else {
+            // the next row's 12 bytes are requested before the current row is processed
+            uint3 pw = *reinterpret_cast<const uint3*>(src + (size_t)sy * spitch + a);
+            uint32_t p0 = pw.x, p1 = pw.y, p2 = pw.z;
+            while (y < y_end) { // uniform
+                const int nsy = min(sy + 1, S.h - 1);
+                const uint3 nw = *reinterpret_cast<const uint3*>(src + (size_t)nsy * spitch + a);
+                const uint32_t n0 = nw.x, n1 = nw.y, n2 = nw.z;
+                Hprev = Hcur;
+                Hcur = hpass(p0, p1, p2);
+                while (y < y_end && yo1 == sy) { // destination rows whose second source row is sy
+                    emit(yo == sy ? Hcur : Hprev, Hcur, w1, y);
+                    if (++y < y_end) {
+                        ty = taps[D.tap_y + y];
+                        yo = (int)(ty & 0xffffu);
+                        w1 = ty >> 16;
+                        yo1 = yo + (w1 ? 1 : 0);
+                    }
+                }
+                ++sy;
+                p0 = n0;
+                p1 = n1;
+                p2 = n2;
+            }
         }
     }
 }
