@@ -74,6 +74,10 @@ struct slamfe_ctx {
     // pinned host staging for the host-pointer calls (allocated on first use):
     // pageable hipMemcpy costs milliseconds per call, pinned copies microseconds
     uint8_t *h_in = nullptr, *h_out = nullptr;
+    // set around run_extract by a host-pointer call of a few frames: the last kernel
+    // then writes counts and rows into these pinned arrays as well
+    slamfe_host_rows host_rows = {nullptr, nullptr, nullptr};
+    bool host_rows_done = false; // ... and says so here
     int32_t* h_cnt = nullptr; // allocated at creation
     uint8_t* h_pin = nullptr;  // general pinned bounce buffer (grows)
     size_t h_pin_bytes = 0;
@@ -523,7 +527,8 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
         ProbeScope ps(c, SLAMFE_STAGE_DESCRIBE);
         KCHK(c, slamfe_launch_orient_describe(s, g, n, c->pyr, c->blur, slot_base, c->nslots, c->kp_key,
                                               c->kp_level, c->kp_count, c->kp_mom, c->kps, c->kp_rot, c->desc,
-                                              c->max_kp, c->p.mode, c->p.patch_size));
+                                              c->max_kp, c->p.mode, c->p.patch_size, c->host_rows));
+        c->host_rows_done = c->host_rows.cnt != nullptr;
         return SLAMFE_OK;
     }
     {
@@ -619,8 +624,11 @@ int export_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kps,
     const size_t K = (size_t)c->max_kp;
     uint8_t* hk = c->h_out;
     uint8_t* hd = c->h_out + (size_t)c->p.max_batch * K * sizeof(slamfe_keypoint);
-    KCHK(c, slamfe_launch_export(c->stream, c->kp_count, c->kps, c->desc, slots[0], c->nslots, c->max_kp, nf,
-                                 (kps || desc) ? 1 : 0, c->h_cnt, hk, hd));
+    // (the extraction's last kernel has written them already if it was told to)
+    if (!c->host_rows_done)
+        KCHK(c, slamfe_launch_export(c->stream, c->kp_count, c->kps, c->desc, slots[0], c->nslots, c->max_kp, nf,
+                                     (kps || desc) ? 1 : 0, c->h_cnt, hk, hd));
+    c->host_rows_done = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int worst = SLAMFE_OK;
     for (int i = 0; i < nf; ++i) {
@@ -856,7 +864,16 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
     }
     tr.mark("stage+h2d");
     std::vector<uint64_t> hd((size_t)n);
+    const bool by_export = n < SLAMFE_FEW_FRAMES && c->max_kp % 4 == 0;
+    c->host_rows_done = false;
+    if (by_export) {
+        const size_t K = (size_t)c->max_kp;
+        c->host_rows.cnt = c->h_cnt;
+        c->host_rows.kps = (kps || desc) ? c->h_out : nullptr;
+        c->host_rows.desc = (kps || desc) ? c->h_out + (size_t)c->p.max_batch * K * sizeof(slamfe_keypoint) : nullptr;
+    }
     rc = run_extract(c, c->in_stage, n, w, h, (int)row, fbytes, channels, hd.data());
+    c->host_rows = {nullptr, nullptr, nullptr};
     if (rc) return rc;
     tr.mark("launches");
     std::vector<int> slots((size_t)n);
@@ -864,8 +881,8 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
         if (frame_handles) frame_handles[i] = hd[(size_t)i];
         slots[(size_t)i] = slot_of(c, hd[(size_t)i]);
     }
-    rc = (n < SLAMFE_FEW_FRAMES && c->max_kp % 4 == 0) ? export_frames(c, slots.data(), n, kps, desc, cap, n_out)
-                                                      : download_frames(c, slots.data(), n, kps, desc, cap, n_out);
+    rc = by_export ? export_frames(c, slots.data(), n, kps, desc, cap, n_out)
+                   : download_frames(c, slots.data(), n, kps, desc, cap, n_out);
     tr.mark("results");
     return rc;
 }

@@ -258,7 +258,7 @@ __device__ __forceinline__ void describe_load(const describe_lane& D, const uint
 // compare the 256 sample pairs; lanes 0..3 store the 32 descriptor bytes.
 __device__ __forceinline__ void describe_finish(const describe_lane& D, const uint4 (&r)[DP_NIT], uint4* my,
                                                 const describe_region& R, int cx, int cy, float2 rot, int lane,
-                                                uint8_t* __restrict__ out32)
+                                                uint8_t* __restrict__ out32, uint8_t* __restrict__ out32_host = nullptr)
 {
 #pragma unroll
     for (int it = 0; it < DP_NIT; ++it)
@@ -292,6 +292,7 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
     if (lane < 4) {
         unsigned long long o = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
         reinterpret_cast<unsigned long long*>(out32)[lane] = o;
+        if (out32_host) reinterpret_cast<unsigned long long*>(out32_host)[lane] = o;
     }
     // the next keypoint's staging must not overtake these LDS reads
     wave_lds_fence();
@@ -358,7 +359,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
                                                          int2* __restrict__ kp_mom,
                                                          slamfe_keypoint* __restrict__ kps,
                                                          float2* __restrict__ kp_rot, uint8_t* __restrict__ desc,
-                                                         int max_kp, int mode, int patch_size, int nframes)
+                                                         int max_kp, int mode, int patch_size, int nframes,
+                                                         slamfe_host_rows host)
 {
     __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_TCOLS];
     const int f = wg_frame();
@@ -369,6 +371,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
     const int wave = __builtin_amdgcn_readfirstlane(wg_item() * 4 + wv);
     const int nwaves = (int)gridDim.y * 4;
     int n = kp_count[slot];
+    // results also go straight to the caller's side (pinned host memory) if asked for:
+    // the frame's count here, records and descriptor rows where they are made
+    if (host.cnt && wave == 0 && lane == 0) host.cnt[f] = n;
     if (n > max_kp) n = max_kp;
     if (wave >= n) return;
     const orient_lane W = orient_setup(lane);
@@ -408,7 +413,18 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
             kps[e] = k;
             kp_rot[e] = rot;
         }
-        if (can_describe) describe_finish(D, r, my, R, cx, cy, rot, lane, desc + e * 32);
+        const size_t he = (size_t)f * max_kp + idx;
+        if (host.kps && lane < 7) { // every lane holds the record: lane i sends dword i of its 28 bytes
+            const uint32_t word = lane == 0 ? __float_as_uint(k.x) : lane == 1 ? __float_as_uint(k.y)
+                                : lane == 2 ? __float_as_uint(k.size) : lane == 3 ? __float_as_uint(k.angle)
+                                : lane == 4 ? __float_as_uint(k.response) : lane == 5 ? (uint32_t)k.octave
+                                                                                       : (uint32_t)k.class_id;
+            reinterpret_cast<uint32_t*>(host.kps + he * sizeof(slamfe_keypoint))[lane] = word;
+        }
+        if (can_describe) describe_finish(D, r, my, R, cx, cy, rot, lane, desc + e * 32, host.desc ? host.desc + he * 32 : nullptr);
+        else if (host.desc && lane < 4) // the row keeps what the slot holds
+            reinterpret_cast<unsigned long long*>(host.desc + he * 32)[lane] =
+                reinterpret_cast<const unsigned long long*>(desc + e * 32)[lane];
     }
 }
 
@@ -481,7 +497,7 @@ int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int n
                                   const uint8_t* blur, int slot_base, int nslots, const uint32_t* kp_key,
                                   const uint32_t* kp_level, const int32_t* kp_count, int32_t* kp_mom,
                                   slamfe_keypoint* kps, float* kp_rot, uint8_t* desc, int max_kp, int mode,
-                                  int patch_size)
+                                  int patch_size, slamfe_host_rows host)
 {
     long long est = 0;
     for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
@@ -489,7 +505,7 @@ int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int n
     // two keypoints per wavefront: a call of a few frames is short of waves, not of work
     hipLaunchKernelGGL(k_orient_describe, frame_grid((int)((est + 7) / 8), nframes), dim3(256), 0, s, g, pyr,
                        blur, slot_base, nslots, kp_key, kp_level, kp_count, reinterpret_cast<int2*>(kp_mom), kps,
-                       reinterpret_cast<float2*>(kp_rot), desc, max_kp, mode, patch_size, nframes);
+                       reinterpret_cast<float2*>(kp_rot), desc, max_kp, mode, patch_size, nframes, host);
     LAUNCH_CHECK();
     return 0;
 }

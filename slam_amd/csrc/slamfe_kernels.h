@@ -23,6 +23,14 @@ typedef struct slamfe_level0 {
     const uint8_t* base;
     size_t frame_stride;
 } slamfe_level0;
+
+/* Where a call of a few frames wants its results besides the frame slots: pinned
+ * host arrays laid out [frame of the call][max_kp rows] (all null: nowhere). */
+typedef struct slamfe_host_rows {
+    int32_t* cnt;
+    uint8_t* kps;
+    uint8_t* desc;
+} slamfe_host_rows;
 int slamfe_launch_pyramid(hipStream_t s, const slamfe_dev_geom& g, int nframes, uint8_t* pyr,
                           const uint32_t* taps, slamfe_level0 l0);
 /* Ingest + all pyramid levels in one launch (a few frames per call); d_in = NULL:
@@ -52,7 +60,7 @@ int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int n
                                   const uint8_t* blur, int slot_base, int nslots, const uint32_t* kp_key,
                                   const uint32_t* kp_level, const int32_t* kp_count, int32_t* kp_mom,
                                   slamfe_keypoint* kps, float* kp_rot, uint8_t* desc, int max_kp, int mode,
-                                  int patch_size);
+                                  int patch_size, slamfe_host_rows host);
 
 /* Counts and (with_rows) keypoint records + descriptor rows of nframes consecutive
  * slots into host-pinned arrays laid out [frame][max_kp]. */
