@@ -527,7 +527,7 @@ int run_extract(slamfe_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int s
         ProbeScope ps(c, SLAMFE_STAGE_DESCRIBE);
         KCHK(c, slamfe_launch_orient_describe(s, g, n, c->pyr, c->blur, slot_base, c->nslots, c->kp_key,
                                               c->kp_level, c->kp_count, c->kp_mom, c->kps, c->kp_rot, c->desc,
-                                              c->max_kp, c->p.mode, c->p.patch_size, c->host_rows));
+                                              c->max_kp, c->p.mode, c->p.patch_size, c->host_rows, c->cur_l0));
         c->host_rows_done = c->host_rows.cnt != nullptr;
         return SLAMFE_OK;
     }

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
                                                          slamfe_keypoint* __restrict__ kps,
                                                          float2* __restrict__ kp_rot, uint8_t* __restrict__ desc,
                                                          int max_kp, int mode, int patch_size, int nframes,
-                                                         slamfe_host_rows host)
+                                                         slamfe_host_rows host, slamfe_level0 l0)
 {
     __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_TCOLS];
     const int f = wg_frame();
@@ -399,7 +399,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
         const bool can_describe = !(cx < 18 || cy < 18 || cx >= w - 22 || cy >= h - 18);
         uint4 x4 = make_uint4(0, 0, 0, 0);
         uint4 r[DP_NIT];
-        if (can_orient) x4 = orient_load(W, pyr + lvl + (size_t)(cy - 15) * pitch + (cx - 15), pitch, lane);
+        // (level 0 may be the caller's frame itself, used in place)
+        const uint8_t* unblurred = l == 0 ? l0.base + (size_t)f * l0.frame_stride : pyr + lvl;
+        if (can_orient) x4 = orient_load(W, unblurred + (size_t)(cy - 15) * pitch + (cx - 15), pitch, lane);
         const describe_region R = describe_region_of(cx, cy);
         if (can_describe) describe_load(D, blur + lvl, pitch >> 4, R, r);
         int2 m = make_int2(0, 0);
@@ -497,7 +499,7 @@ int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int n
                                   const uint8_t* blur, int slot_base, int nslots, const uint32_t* kp_key,
                                   const uint32_t* kp_level, const int32_t* kp_count, int32_t* kp_mom,
                                   slamfe_keypoint* kps, float* kp_rot, uint8_t* desc, int max_kp, int mode,
-                                  int patch_size, slamfe_host_rows host)
+                                  int patch_size, slamfe_host_rows host, slamfe_level0 l0)
 {
     long long est = 0;
     for (int l = 0; l < g.nlevels; ++l) est += g.lv[l].quota;
@@ -505,7 +507,7 @@ int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int n
     // two keypoints per wavefront: a call of a few frames is short of waves, not of work
     hipLaunchKernelGGL(k_orient_describe, frame_grid((int)((est + 7) / 8), nframes), dim3(256), 0, s, g, pyr,
                        blur, slot_base, nslots, kp_key, kp_level, kp_count, reinterpret_cast<int2*>(kp_mom), kps,
-                       reinterpret_cast<float2*>(kp_rot), desc, max_kp, mode, patch_size, nframes, host);
+                       reinterpret_cast<float2*>(kp_rot), desc, max_kp, mode, patch_size, nframes, host, l0);
     LAUNCH_CHECK();
     return 0;
 }

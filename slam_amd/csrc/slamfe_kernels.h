@@ -60,7 +60,7 @@ int slamfe_launch_orient_describe(hipStream_t s, const slamfe_dev_geom& g, int n
                                   const uint8_t* blur, int slot_base, int nslots, const uint32_t* kp_key,
                                   const uint32_t* kp_level, const int32_t* kp_count, int32_t* kp_mom,
                                   slamfe_keypoint* kps, float* kp_rot, uint8_t* desc, int max_kp, int mode,
-                                  int patch_size, slamfe_host_rows host);
+                                  int patch_size, slamfe_host_rows host, slamfe_level0 l0);
 
 /* Counts and (with_rows) keypoint records + descriptor rows of nframes consecutive
  * slots into host-pinned arrays laid out [frame][max_kp]. */

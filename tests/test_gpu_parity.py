@@ -272,6 +272,30 @@ def test_extract_fuzz_parameters():
     assert checked > 5000
 
 
+@pytest.mark.parametrize("nlevels,scale", [(1, 1.2), (2, 1.2), (8, 1.1), (8, 2.0)])
+@pytest.mark.parametrize("nframes", [1, 3])
+def test_extract_frames_usable_in_place(nlevels, scale, nframes):
+    # gray frames whose width is a multiple of 64 already have level 0's layout and are
+    # read where they lie (no copy into the pyramid buffer): every kernel that reads
+    # level 0 must take it from there, in calls of a few frames too, with one level
+    # (no pyramid kernel at all) and with geometries the one-launch pyramid cannot hold
+    import torch
+    from slam_amd.frontend import FrontEnd
+    w, h = 320, 240
+    frames = synth.frame_stream(w, h, nframes, seed=40 + nlevels)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=500, nlevels=nlevels, scale_factor=scale,
+                  max_width=w, max_height=h, max_batch=4, map_capacity=0) as fe:
+        want = [O.extract(oracle_params(fe), fr) for fr in frames]
+        for f, (kps, desc) in zip(fe.extract_batch(list(frames)), want):  # host frames
+            assert_frame_equal(f, kps, desc)
+        d = torch.from_numpy(np.ascontiguousarray(frames)).cuda()        # resident frames, in place
+        torch.cuda.synchronize()
+        handles = fe.extract_resident(d.data_ptr(), nframes, w, h, w, w * h, 1)
+        for hd, (kps, desc) in zip(handles, want):
+            assert_frame_equal(fe.frame_download(int(hd)), kps, desc)
+        assert sum(len(k) for k, _ in want) > 100
+
+
 # ------------------------------------------------------------------ matching
 @pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (1, 2), (257, 63), (64, 1000), (5, 0),
                                    (3001, 2999), (100, 20000),
@@ -921,3 +945,51 @@ def test_reproject_and_triangulate_a_million_points():
         got = fe.triangulate(P1, P2, p1, p2)
         want = O.triangulate(P1, P2, p1, p2)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------- float routines against numpy, not shared source
+def test_float_routines_against_numpy_definitions():
+    """The keypoint angle (fastAtan2), the descriptor rotation (cos / sin) and the
+    triangulation share one source file between the kernels and the CPU checker; here
+    the GPU results are held against independent numpy definitions instead: moments
+    summed pixel by pixel and numpy's arctan2, the descriptor evaluated with numpy's
+    cos / sin, and numpy.linalg.svd in float64."""
+    import slow_defs as S
+    from slam_amd.frontend import FrontEnd
+    from slam_amd import tables
+    img = synth.textured_canvas(320, 240, 77)
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=400, nlevels=1, max_width=320,
+                  max_height=240, max_batch=1, map_capacity=0) as fe:
+        f = fe.extract_keypoints(img)
+        assert len(f) > 200
+        blurred = S.blur7(img)
+        worst = 0.0
+        ndesc = 0
+        for k, d in zip(f.keypoints, f.descriptors):
+            cx, cy = int(k["x"]), int(k["y"])
+            assert k["octave"] == 0 and cx == k["x"] and cy == k["y"]
+            m10, m01 = S.ic_moments(img, cx, cy)
+            want = np.degrees(np.arctan2(float(m01), float(m10))) % 360.0
+            diff = abs((float(k["angle"]) - want + 180.0) % 360.0 - 180.0)
+            worst = max(worst, diff)
+            # cv::fastAtan2 is a polynomial good to 0.3 degrees
+            assert diff < 0.3, (cx, cy, k["angle"], want)
+            # the descriptor from numpy's cos / sin of the angle the GPU reports
+            assert np.array_equal(d, S.brief256(blurred, cx, cy, k["angle"], tables.PATTERN)), (cx, cy)
+            ndesc += 1
+        assert ndesc == len(f) and worst > 0.0  # (a polynomial, not libm: some error is expected)
+        # triangulation: homogeneous least squares by float64 SVD
+        P1, P2, p1, p2 = synth.two_view_scene(300, 640, 480, 5)
+        got = fe.triangulate(P1, P2, p1, p2).astype(np.float64)
+        P1d, P2d = np.asarray(P1, np.float64).reshape(3, 4), np.asarray(P2, np.float64).reshape(3, 4)
+        checked = 0
+        for (x1, y1), (x2, y2), g in zip(np.asarray(p1, np.float64), np.asarray(p2, np.float64), got):
+            A = np.stack([x1 * P1d[2] - P1d[0], y1 * P1d[2] - P1d[1], x2 * P2d[2] - P2d[0], y2 * P2d[2] - P2d[1]])
+            sv = np.linalg.svd(A, compute_uv=False)
+            v = np.linalg.svd(A)[2][3]
+            if abs(v[3]) < 1e-6 or (sv[2] - sv[3]) / sv[0] < 1e-3:
+                continue  # ill-conditioned pair: float32 and float64 may differ freely
+            want = v[:3] / v[3]
+            assert np.abs(g - want).max() <= 2e-3 * max(1.0, np.abs(want).max()), (g, want)
+            checked += 1
+        assert checked > 200
