@@ -296,6 +296,33 @@ def test_extract_frames_usable_in_place(nlevels, scale, nframes):
         assert sum(len(k) for k, _ in want) > 100
 
 
+@pytest.mark.parametrize("kernel", [abi.MATCH_POPCOUNT, abi.MATCH_MATRIX])
+def test_match_extreme_descriptors_among_random_ones(kernel):
+    # all-zero and all-one rows among random ones: distances 0 and 256 and queries of
+    # popcount 0 and 256, the ends of the range the matrix-core keys have to hold
+    # (key = 16 * (distance + 256 - popcount(query)) + row fraction); many exact ties
+    from slam_amd.frontend import FrontEnd
+    rng = np.random.default_rng(11)
+    nq, nt = 300, 2100
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q[::7] = 0
+    q[3::7] = 255
+    t[5::11] = 0
+    t[6::11] = 255
+    t[40:45] = q[10]        # exact copies: distance 0, ties broken by the lower row
+    t[2050:2052] = q[10]
+    with FrontEnd(mode=abi.MODE_ORB, max_width=64, max_height=64, max_batch=1, map_capacity=0,
+                  match_kernel=kernel) as fe:
+        for qq, tt in ((q, t), (q, t[:33]), (q[:129], np.full((70, 32), 255, np.uint8)),
+                       (np.zeros((130, 32), np.uint8), np.full((64, 32), 255, np.uint8))):
+            got = fe.knn_match(qq, tt)
+            want = O.match_knn2(qq, tt)
+            for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+                assert np.array_equal(got[name], want[name]), (kernel, name, len(qq), len(tt))
+        assert want["d0"].max() == 256
+
+
 # ------------------------------------------------------------------ matching
 @pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (1, 2), (257, 63), (64, 1000), (5, 0),
                                    (3001, 2999), (100, 20000),
