@@ -26,6 +26,8 @@ def main():
     bad = 0
     for case in range(cases):
         w, h = int(rng.integers(64, 1300)), int(rng.integers(64, 760))
+        if case % 2:  # widths whose rows already have level 0's layout (frames used in place)
+            w = 64 * int(rng.integers(1, 21))
         kw = dict(mode=int(rng.integers(0, 2)), fast_threshold=int(rng.integers(3, 80)),
                   nfeatures=int(rng.integers(10, 6000)), nlevels=int(rng.integers(1, 9)),
                   scale_factor=float(rng.choice([1.05, 1.1, 1.2, 1.25, 1.5, 1.7, 2.0])),
@@ -37,6 +39,20 @@ def main():
             kps, desc = O.extract(params_of(fe), img)
             ok = len(f) == len(kps) and all(np.array_equal(f.keypoints[n], kps[n]) for n in kps.dtype.names) \
                 and np.array_equal(f.descriptors, desc)
+            # a batch through the host-pointer call and the resident call, in the same context
+            nb = int(rng.choice([2, 3, 9])) if w * h <= 400 * 300 else 2
+            if case % 4 < 2:
+                import torch
+                frames = [img] + [synth.textured_canvas(w, h, 5000 + case * 16 + i) for i in range(1, nb)]
+                want_b = [O.extract(params_of(fe), fr) for fr in frames]
+                with FrontEnd(max_width=w, max_height=h, map_capacity=0, max_batch=nb, **kw) as fb:
+                    got_b = fb.extract_batch(frames)
+                    d = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).cuda()
+                    torch.cuda.synchronize()
+                    got_r = [fb.frame_download(int(hd)) for hd in fb.extract_resident(d.data_ptr(), nb, w, h, w, w * h, 1)]
+                for g, (kb, db) in list(zip(got_b, want_b)) + list(zip(got_r, want_b)):
+                    ok = ok and len(g) == len(kb) and all(np.array_equal(g.keypoints[n], kb[n]) for n in kb.dtype.names) \
+                        and np.array_equal(g.descriptors, db)
             nq, nt = int(rng.integers(0, 3000)), int(rng.integers(0, 5000))
             q, t = synth.descriptor_sets(max(nq, 1), max(nt, 1), seed=case, dup_percent=int(rng.integers(0, 20)))
             q, t = q[:nq], t[:nt]
