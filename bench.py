@@ -473,6 +473,12 @@ def leg_extract_config(name, w, h, nfeat, total_frames, distinct, dev, local_ran
 
 
 def main():
+    # Standard output carries the one JSON line and nothing else: whatever libraries
+    # print there meanwhile (RCCL's version banner at the first collective, for one)
+    # is sent to standard error.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -816,8 +822,11 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
