@@ -864,7 +864,10 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
     }
     tr.mark("stage+h2d");
     std::vector<uint64_t> hd((size_t)n);
-    const bool by_export = n < SLAMFE_FEW_FRAMES && c->max_kp % 4 == 0;
+    // results: counts and rows are written into pinned memory by a kernel (one wait, no
+    // round trip for the counts first), by the extraction's last kernel itself in calls
+    // of a few frames
+    const bool by_export = c->max_kp % 4 == 0;
     c->host_rows_done = false;
     if (by_export) {
         const size_t K = (size_t)c->max_kp;
