@@ -336,6 +336,43 @@ def window_gate_tests(xy, uv, radius, max_w, max_h):
     return int(win[ky, kx].sum())
 
 
+def leg_two_streams(frames, B, dev, local_rank, steps):
+    """The headline workload from two contexts on two HIP streams at once (each its
+    own 256-frame batches): kernels bound by different units (vector issue in FAST +
+    blur, L1 lines in orientation, matrix pipe in matching) share the chip.  Reported
+    beside the headline, which stays one stream so that its per-kernel times are those
+    of kernels that have the chip to themselves."""
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    fes = [FrontEnd(mode=abi.MODE_ORB, fast_threshold=THR, nfeatures=NFEAT, max_width=W, max_height=H, max_batch=B,
+                    frame_slots=2 * B + 2, device_id=local_rank, stream=st.cuda_stream, map_capacity=0)
+           for st in streams]
+    outs = [torch.empty((B, fes[0].max_keypoints, 16), dtype=torch.uint8, device=dev) for _ in fes]
+    last = [None, None]
+
+    def step():
+        for i, f in enumerate(fes):
+            h = f.extract_resident(frames.data_ptr(), B, W, H, W, W * H, 1)
+            first = int(h[0])
+            if last[i] is not None:
+                f.match_resident_batch(first - 1, first, B, outs[i].data_ptr())
+            last[i] = first + B - 1
+
+    try:
+        for _ in range(30):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+    finally:
+        for f in fes:
+            f.close()
+    return {"what": "two contexts / HIP streams, 256 frames per stream and step", "frames_per_s": round(2 * B * steps / el, 1),
+            "ms_per_step_of_512_frames": round(el / steps * 1e3, 4)}
+
+
 def leg_config2(local_rank, check):
     """BASELINE config 2: KITTI-size 1241x376 stream, 3000 features per frame,
     search by projection against 20 000 local map points; one frame at a time
@@ -786,7 +823,13 @@ def main():
     }
     for f in fes:
         f.close()
-    del frames, match_outs
+    del match_outs
+    if S == 1 and not args.no_legs and world == 1 and not multi:
+        try:
+            result["two_streams"] = leg_two_streams(frames, B, dev, local_rank, max(args.steps, 20))
+        except Exception as e:  # the headline number must survive a failure of this leg
+            result["two_streams"] = {"error": repr(e)}
+    del frames
     check = not args.no_cpu
 
     # The timed batch against the CPU checker (rank 0's frames): keypoints,
