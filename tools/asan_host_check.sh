@@ -18,6 +18,10 @@ if [ "$1" != "run" ]; then
         -I"$ROOT/oracle" "$ROOT/tests/cpp/test_host_adapter.cpp" -o "$B/test_host_adapter" \
         -L"$B" -lslamfe -L"$ROOT/oracle" -lslamfe_oracle -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../oracle' \
         -Wl,-rpath,/opt/rocm/lib
+    ${CL}++ -O1 -g -std=c++14 -fsanitize=address -fno-omit-frame-pointer -I"$ROOT/include" -I"$ROOT/slam_amd/host" \
+        -I"$ROOT/oracle" "$ROOT/tests/cpp/test_tracking_loop.cpp" -o "$B/test_tracking_loop" \
+        -L"$B" -lslamfe -L"$ROOT/oracle" -lslamfe_oracle -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../oracle' \
+        -Wl,-rpath,/opt/rocm/lib
     $CL -x c -O1 -g -std=c99 -fsanitize=address -fno-omit-frame-pointer -I"$ROOT/include" \
         "$ROOT/tests/cpp/abi_batch_check.c" -o "$B/abi_batch_check" -L"$B" -lslamfe -Wl,-rpath,'$ORIGIN' \
         -Wl,-rpath,/opt/rocm/lib
@@ -29,7 +33,9 @@ python - <<'PY'
 from slam_amd import synth
 a, b = synth.frame_pair(640, 480)
 a.tofile("asan_build/a.raw"); b.tofile("asan_build/b.raw")
+synth.frame_stream(320, 240, 40, seed=15).tofile("asan_build/stream.raw")
 PY
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0
 "$B/test_host_adapter" asan_build/a.raw asan_build/b.raw 640 480
 "$B/abi_batch_check"
+"$B/test_tracking_loop" asan_build/stream.raw 320 240 40 3 2
