@@ -153,6 +153,40 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t* __restrict__ quer
     }
 }
 
+__device__ __forceinline__ void top2_push(uint32_t k, uint32_t& b1, uint32_t& b2)
+{
+    uint32_t mx = max(k, b1);
+    b1 = min(k, b1);
+    b2 = min(mx, b2);
+}
+
+__device__ __forceinline__ void match_emit(uint32_t b1, uint32_t b2, int qi, float ratio,
+                                           slamfe_match2* __restrict__ out,
+                                           uint64_t* __restrict__ out_keys, int64_t train_base)
+{
+    const uint32_t mask = (1u << SLAMFE_MKEY_SHIFT) - 1u;
+    if (out_keys) {
+        uint64_t k0 = ~0ULL, k1 = ~0ULL;
+        if (b1 != SLAMFE_MKEY_NONE)
+            k0 = ((uint64_t)(b1 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b1 & mask));
+        if (b2 != SLAMFE_MKEY_NONE)
+            k1 = ((uint64_t)(b2 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b2 & mask));
+        out_keys[(size_t)qi * 2] = k0;
+        out_keys[(size_t)qi * 2 + 1] = k1;
+    }
+    if (out) {
+        slamfe_match2 m;
+        m.idx0 = b1 != SLAMFE_MKEY_NONE ? (int32_t)(b1 & mask) : -1;
+        m.idx1 = b2 != SLAMFE_MKEY_NONE ? (int32_t)(b2 & mask) : -1;
+        m.d0 = (uint16_t)(b1 != SLAMFE_MKEY_NONE ? b1 >> SLAMFE_MKEY_SHIFT : 0);
+        m.d1 = (uint16_t)(b2 != SLAMFE_MKEY_NONE ? b2 >> SLAMFE_MKEY_SHIFT : 0);
+        m.nfound = (uint8_t)((m.idx0 >= 0) + (m.idx1 >= 0));
+        m.ratio_pass = (uint8_t)(m.nfound == 2 && (float)m.d0 < ratio * (float)m.d1);
+        m.reserved[0] = m.reserved[1] = 0;
+        out[qi] = m;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K8m  the same brute-force Hamming k=2 on the matrix cores, in FP4.
 //
@@ -221,6 +255,16 @@ __device__ __forceinline__ uint32_t bits8_to_nibbles(uint32_t x)
     return (t | (t << 3)) & 0x11111111u;
 }
 
+// Where the finished match rows / shard keys go when a workgroup sees the whole
+// train set (one chunk): the kernel then emits them itself and no merge runs.
+struct slamfe_match_direct {
+    int on;
+    float ratio;
+    slamfe_match2* out;
+    uint64_t* keys;
+    int64_t train_base;
+};
+
 #ifdef SLAMFE_STAMPS
 // Diagnostic build only: shader-clock and wall-clock stamps of wave 0 of 64 sampled
 // workgroups of k_match_mfma (kernel entry, stage loop entry and exit, kernel
@@ -253,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                     const uint32_t* __restrict__ train, int nt_imm,
                                                     const int32_t* __restrict__ nt_dev,
                                                     uint32_t* __restrict__ part, slamfe_pair_slots ps,
-                                                    slamfe_match_geo mg)
+                                                    slamfe_match_geo mg, slamfe_match_direct direct)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sA[3][MM_SUB][MM_TILE * MM_ROW];
     MM_STAMP(0);
@@ -273,6 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         nq_dev += sq;
         nt_dev += st;
         part += (size_t)pair * mg.nchunks * mg.cap * 2;
+        if (direct.out) direct.out += (size_t)pair * mg.cap;
     }
     const int nq = nq_dev ? min(*nq_dev, mg.cap) : nq_imm;
     const int nt = nt_dev ? min(*nt_dev, mg.cap) : nt_imm;
@@ -289,9 +334,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (j0 >= j1) { // an empty train set: every query of the workgroup gets "none"
         for (int blk = 0; blk < 2; ++blk) {
             int qi = qfirst + 32 * blk;
-            if (h == 0 && qi < nq)
-                reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
-                    make_uint2(SLAMFE_MKEY_NONE, SLAMFE_MKEY_NONE);
+            if (h == 0 && qi < nq) {
+                if (direct.on)
+                    match_emit(SLAMFE_MKEY_NONE, SLAMFE_MKEY_NONE, qi, direct.ratio, direct.out, direct.keys, direct.train_base);
+                else
+                    reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
+                        make_uint2(SLAMFE_MKEY_NONE, SLAMFE_MKEY_NONE);
+            }
         }
         return;
     }
@@ -488,8 +537,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const uint32_t row = (ki & 16383u) - MM_BIAS + last + (uint32_t)j0;
                 return (d << SLAMFE_MKEY_SHIFT) | row;
             };
-            reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
-                make_uint2(conv(m1), conv(m2));
+            if (direct.on) // the only chunk: these are the query's final two
+                match_emit(conv(m1), conv(m2), qi, direct.ratio, direct.out, direct.keys, direct.train_base);
+            else
+                reinterpret_cast<uint2*>(part)[(size_t)chunk * mg.part_sc + (size_t)qi * mg.part_sq] =
+                    make_uint2(conv(m1), conv(m2));
         }
     }
     MM_STAMP(3);
@@ -498,40 +550,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         g_mm_stamps[(blockIdx.x >> 5) * 16 + 8] = (unsigned long long)nstages;
     if (blockIdx.x < 4096u && threadIdx.x == 0) g_mm_where[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-}
-
-__device__ __forceinline__ void top2_push(uint32_t k, uint32_t& b1, uint32_t& b2)
-{
-    uint32_t mx = max(k, b1);
-    b1 = min(k, b1);
-    b2 = min(mx, b2);
-}
-
-__device__ __forceinline__ void match_emit(uint32_t b1, uint32_t b2, int qi, float ratio,
-                                           slamfe_match2* __restrict__ out,
-                                           uint64_t* __restrict__ out_keys, int64_t train_base)
-{
-    const uint32_t mask = (1u << SLAMFE_MKEY_SHIFT) - 1u;
-    if (out_keys) {
-        uint64_t k0 = ~0ULL, k1 = ~0ULL;
-        if (b1 != SLAMFE_MKEY_NONE)
-            k0 = ((uint64_t)(b1 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b1 & mask));
-        if (b2 != SLAMFE_MKEY_NONE)
-            k1 = ((uint64_t)(b2 >> SLAMFE_MKEY_SHIFT) << 32) | (uint64_t)(train_base + (b2 & mask));
-        out_keys[(size_t)qi * 2] = k0;
-        out_keys[(size_t)qi * 2 + 1] = k1;
-    }
-    if (out) {
-        slamfe_match2 m;
-        m.idx0 = b1 != SLAMFE_MKEY_NONE ? (int32_t)(b1 & mask) : -1;
-        m.idx1 = b2 != SLAMFE_MKEY_NONE ? (int32_t)(b2 & mask) : -1;
-        m.d0 = (uint16_t)(b1 != SLAMFE_MKEY_NONE ? b1 >> SLAMFE_MKEY_SHIFT : 0);
-        m.d1 = (uint16_t)(b2 != SLAMFE_MKEY_NONE ? b2 >> SLAMFE_MKEY_SHIFT : 0);
-        m.nfound = (uint8_t)((m.idx0 >= 0) + (m.idx1 >= 0));
-        m.ratio_pass = (uint8_t)(m.nfound == 2 && (float)m.d0 < ratio * (float)m.d1);
-        m.reserved[0] = m.reserved[1] = 0;
-        out[qi] = m;
-    }
 }
 
 // Fold per-chunk top-2 keys.  Output either match rows (ratio test applied) or
@@ -696,13 +714,16 @@ int slamfe_launch_match(hipStream_t s, const uint8_t* d_query, int nq, const int
     // bits of its keys: a chunk may not span more tiles than MM_BIAS allows
     if (qpt == 64 && ((chunk_rows + MM_TILE - 1) / MM_TILE - 1) * MM_TILE > (int)MM_BIAS)
         return (int)hipErrorInvalidValue;
+    // one chunk (frame pairs): the matrix-core kernel writes the rows itself
+    slamfe_match_direct direct = {qpt == 64 && nchunks == 1, ratio, d_out, d_keys, train_base};
     if (qpt == 64)
-        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
+        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg, direct);
     else if (qpt == 1)
         hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, q32, nq, d_nq, t32, nt, d_nt, part, ps, mg);
     else
         return (int)hipErrorInvalidValue;
     LAUNCH_CHECK();
+    if (direct.on) return 0;
     if (wide)
         hipLaunchKernelGGL(k_match_merge<64>, dim3((nq_grid + 3) / 4, npairs), dim3(256), 0, s, part, nq,
                            d_nq, d_nt, nt, ratio, d_out, d_keys, train_base, ps, mg);
