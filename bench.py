@@ -276,6 +276,7 @@ def leg_host_path(local_rank):
                                      "descriptors back to host memory (PCIe both ways)"}
     single = {}
     native = os.path.join(ROOT, "tools", "single_call_bench")
+    native_cxx = os.path.join(ROOT, "tools", "cxx_adapter_bench")
     cases = (("vga_orb_2000_thr20", W, H, NFEAT, THR, abi.MODE_ORB),
              ("kitti_1241x376_provided_thr30", 1241, 376, 10000, 30, abi.MODE_PROVIDED),
              ("kitti_1241x376_orb_3000_thr20", 1241, 376, 3000, 20, abi.MODE_ORB))
@@ -308,6 +309,10 @@ def leg_host_path(local_rank):
                 b.tofile(fb)
                 r = subprocess.run([native, fa, fb, str(w), str(h), str(mode), str(thr), str(nf), "200"],
                                    capture_output=True, text=True, timeout=120)
+                r2 = None
+                if os.path.exists(native_cxx):
+                    r2 = subprocess.run([native_cxx, fa, fb, str(w), str(h), str(mode), str(thr), str(nf), "200"],
+                                        capture_output=True, text=True, timeout=120)
             if r.returncode == 0:
                 c = json.loads(r.stdout.strip().splitlines()[-1])
                 c["frames_per_s"] = round(1e3 / c["extract_plus_match_mean_ms"], 1)
@@ -315,6 +320,18 @@ def leg_host_path(local_rank):
                 single[name + "_c_caller"] = c
             else:
                 single[name + "_c_caller"] = {"error": r.stderr[-300:]}
+            # ... and through the C++ host layer the patched Init.cc binds: containers filled,
+            # knnMatch on the two frames' handles, the hand-over of Init.cc:322-323
+            if r2 is not None and r2.returncode == 0:
+                c = json.loads(r2.stdout.strip().splitlines()[-1])
+                c["frames_per_s"] = round(1e3 / c["extract_plus_match_mean_ms"], 1)
+                c["caller"] = "C++14 slamfe::FrontEnd (tools/cxx_adapter_bench.cpp)"
+                cc = single.get(name + "_c_caller", {})
+                if "extract_plus_match_ms" in cc:
+                    c["over_c_caller"] = round(c["extract_plus_match_ms"] / cc["extract_plus_match_ms"], 3)
+                single[name + "_cxx_adapter"] = c
+            elif r2 is not None:
+                single[name + "_cxx_adapter"] = {"error": r2.stderr[-300:]}
     out["single_call_ms"] = single
     return out
 

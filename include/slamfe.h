@@ -82,8 +82,9 @@ extern "C" {
 
 /* The two brute-force Hamming kernels behind knnMatch (Init.cc:131); results are
  * identical.  POPCOUNT: v_xor / v_bcnt on the vector ALU.  MATRIX: the bit
- * vectors expanded to int8 and multiplied on the matrix cores (about twice as
- * fast from 128 queries up).  AUTO: MATRIX from 128 queries up, else POPCOUNT. */
+ * vectors expanded to 4-bit floating-point operands (a bit is a nibble) and
+ * multiplied on the matrix cores, exactly; about four times as fast as POPCOUNT
+ * on large jobs.  AUTO: MATRIX from 128 queries up, else POPCOUNT. */
 #define SLAMFE_MATCH_AUTO 0
 #define SLAMFE_MATCH_POPCOUNT 1
 #define SLAMFE_MATCH_MATRIX 2
@@ -161,6 +162,18 @@ int slamfe_extract(slamfe_ctx* ctx, const uint8_t* img, int w, int h, int stride
                    slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
                    uint64_t* frame_handle);
 
+/* Init.cc:75-78 as slamfe_extract, without the copy into caller arrays: *kps and
+ * *desc point at the *n_out keypoint records and 32-byte descriptor rows in the
+ * context's own page-locked result arrays (host memory, read-only for the
+ * caller), valid until the next extraction or download call on this context.  A
+ * host layer that fills containers of its own (std::vector<cv::KeyPoint>, a
+ * cv::Mat of n rows) copies exactly n records and rows from there, instead of
+ * offering arrays sized for the worst case.  Fails with SLAMFE_E_CAPACITY (and
+ * *n_out = needed count) only if the context's max_keypoints is too small. */
+int slamfe_extract_view(slamfe_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                        const slamfe_keypoint** kps, const uint8_t** desc, int* n_out,
+                        uint64_t* frame_handle);
+
 /* Init.cc:75-78 for n <= max_batch frames of one size (the reference takes one
  * frame per loop iteration, Init.cc:124-130; a batch is n iterations); frame i uses imgs[i],
  * kps + i*cap, desc + i*cap*32, n_out[i], frame_handles[i].  kps and desc may
@@ -203,10 +216,19 @@ int slamfe_match_knn2(slamfe_ctx* ctx, const uint8_t* query, int nq, const uint8
 
 /* Init.cc:131-153 on two device-resident frames: rows to out[0 .. *nq_out), at
  * most cap.  out may be NULL: then only *nq_out (the query frame's keypoint
- * count) is returned; callers that want the rows on the device use
- * slamfe_match_resident with a buffer of their own. */
+ * count) is returned and no matching is done; callers that want the rows on the
+ * device use slamfe_match_resident with a buffer of their own. */
 int slamfe_match_frames(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
                         slamfe_match2* out, int cap, int* nq_out);
+
+/* Init.cc:131-153 as slamfe_match_frames, without the copy into a caller array:
+ * *rows points at the *nq_out match rows in the context's page-locked bounce
+ * buffer (host memory, read-only for the caller), valid until the next call on
+ * this context.  This is the call behind the host layer's knnMatch on two frame
+ * handles: the previous and the current frame are already on the device
+ * (Init.cc:322-323 hands descriptors2 on to descriptors1), so nothing is uploaded. */
+int slamfe_match_frames_view(slamfe_ctx* ctx, uint64_t query_frame, uint64_t train_frame,
+                             const slamfe_match2** rows, int* nq_out);
 
 /* Asynchronous form of Init.cc:131-153: both frames device-resident, result written to
  * d_out[0..max_keypoints) (device memory), row counts read on the device.  Rows

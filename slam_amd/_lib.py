@@ -27,6 +27,8 @@ SIGNATURES = {
     "slamfe_last_error": (C.c_char_p, [ctxp]),
     "slamfe_extract": (C.c_int, [ctxp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int,
                                  i32p, u64p]),
+    "slamfe_extract_view": (C.c_int, [ctxp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp),
+                                      C.POINTER(vp), i32p, u64p]),
     "slamfe_extract_scaled_bgr": (C.c_int, [ctxp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                             vp, i32p, i32p, vp, vp, C.c_int, i32p, u64p]),
     "slamfe_extract_batch": (C.c_int, [ctxp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -36,6 +38,7 @@ SIGNATURES = {
     "slamfe_frame_download": (C.c_int, [ctxp, C.c_uint64, vp, vp, C.c_int, i32p]),
     "slamfe_match_knn2": (C.c_int, [ctxp, vp, C.c_int, vp, C.c_int, vp]),
     "slamfe_match_frames": (C.c_int, [ctxp, C.c_uint64, C.c_uint64, vp, C.c_int, i32p]),
+    "slamfe_match_frames_view": (C.c_int, [ctxp, C.c_uint64, C.c_uint64, C.POINTER(vp), i32p]),
     "slamfe_match_resident": (C.c_int, [ctxp, C.c_uint64, C.c_uint64, vp]),
     "slamfe_match_resident_batch": (C.c_int, [ctxp, C.c_uint64, C.c_uint64, C.c_int, vp]),
     "slamfe_debug_time_stage": (C.c_int, [ctxp, C.c_int, C.c_int, C.c_int, f32p]),

@@ -557,7 +557,7 @@ int ensure_host_staging(slamfe_ctx* c)
 // Copy the results of `nf` resident frames (slots[i]) to the caller: one
 // transfer + wait for the counts, one for the rows, through pinned memory.
 int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kps, uint8_t* desc,
-                    int cap, int* n_out)
+                    int cap, int* n_out, bool view = false)
 {
     int rc = ensure_host_staging(c);
     if (rc) return rc;
@@ -580,7 +580,7 @@ int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kp
                          c->max_kp);
             continue;
         }
-        if ((kps || desc) && n > cap) {
+        if (!view && (kps || desc) && n > cap) {
             worst = fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the caller's capacity %d", n, cap);
             continue;
         }
@@ -594,18 +594,18 @@ int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kp
         while (i1 < nf && slots[i1] == slots[i1 - 1] + 1) ++i1;
         int most = 0;
         for (int i = i0; i < i1; ++i) most = std::max(most, ncopy[(size_t)i]);
-        if (most > 0 && kps)
+        if (most > 0 && (kps || view))
             HIPCHK(c, hipMemcpy2DAsync(hk + (size_t)i0 * K, K * sizeof(slamfe_keypoint),
                                        c->kps + (size_t)slots[i0] * K, K * sizeof(slamfe_keypoint),
                                        (size_t)most * sizeof(slamfe_keypoint), (size_t)(i1 - i0),
                                        hipMemcpyDeviceToHost, s));
-        if (most > 0 && desc)
+        if (most > 0 && (desc || view))
             HIPCHK(c, hipMemcpy2DAsync(hd + (size_t)i0 * K * 32, K * 32, c->desc + (size_t)slots[i0] * K * 32,
                                        K * 32, (size_t)most * 32, (size_t)(i1 - i0), hipMemcpyDeviceToHost, s));
         i0 = i1;
     }
     HIPCHK(c, hipStreamSynchronize(s));
-    for (int i = 0; i < nf; ++i) {
+    for (int i = 0; i < nf && !view; ++i) {
         size_t n = (size_t)ncopy[(size_t)i];
         if (n && kps) memcpy(kps + (size_t)i * cap, hk + (size_t)i * K, n * sizeof(slamfe_keypoint));
         if (n && desc) memcpy(desc + (size_t)i * cap * 32, hd + (size_t)i * K * 32, n * 32);
@@ -617,7 +617,7 @@ int download_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kp
 // a call of a few frames: one kernel writes counts and rows into the pinned
 // staging arrays, one wait, then the copies into the caller's arrays.
 int export_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kps, uint8_t* desc, int cap,
-                  int* n_out)
+                  int* n_out, bool view = false)
 {
     int rc = ensure_host_staging(c);
     if (rc) return rc;
@@ -627,7 +627,7 @@ int export_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kps,
     // (the extraction's last kernel has written them already if it was told to)
     if (!c->host_rows_done)
         KCHK(c, slamfe_launch_export(c->stream, c->kp_count, c->kps, c->desc, slots[0], c->nslots, c->max_kp, nf,
-                                     (kps || desc) ? 1 : 0, c->h_cnt, hk, hd));
+                                     (kps || desc || view) ? 1 : 0, c->h_cnt, hk, hd));
     c->host_rows_done = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int worst = SLAMFE_OK;
@@ -640,6 +640,7 @@ int export_frames(slamfe_ctx* c, const int* slots, int nf, slamfe_keypoint* kps,
                          c->max_kp);
             continue;
         }
+        if (view) continue; // the rows stay where they are: the caller reads them in place
         if ((kps || desc) && n > cap) {
             worst = fail(c, SLAMFE_E_CAPACITY, "%d keypoints exceed the caller's capacity %d", n, cap);
             continue;
@@ -825,9 +826,10 @@ int slamfe_extract_resident(slamfe_ctx* c, const void* d_imgs, int n, int w, int
                        frame_handles);
 }
 
-int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride,
-                         int channels, slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
-                         uint64_t* frame_handles)
+namespace {
+int extract_host_frames(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride,
+                        int channels, slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                        uint64_t* frame_handles, bool view)
 {
     if (!c || !imgs) return SLAMFE_E_INVALID;
     PhaseTrace tr("extract_batch");
@@ -872,8 +874,9 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
     if (by_export) {
         const size_t K = (size_t)c->max_kp;
         c->host_rows.cnt = c->h_cnt;
-        c->host_rows.kps = (kps || desc) ? c->h_out : nullptr;
-        c->host_rows.desc = (kps || desc) ? c->h_out + (size_t)c->p.max_batch * K * sizeof(slamfe_keypoint) : nullptr;
+        const bool rows = kps || desc || view;
+        c->host_rows.kps = rows ? c->h_out : nullptr;
+        c->host_rows.desc = rows ? c->h_out + (size_t)c->p.max_batch * K * sizeof(slamfe_keypoint) : nullptr;
     }
     rc = run_extract(c, c->in_stage, n, w, h, (int)row, fbytes, channels, hd.data());
     c->host_rows = {nullptr, nullptr, nullptr};
@@ -884,10 +887,37 @@ int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w
         if (frame_handles) frame_handles[i] = hd[(size_t)i];
         slots[(size_t)i] = slot_of(c, hd[(size_t)i]);
     }
-    rc = by_export ? export_frames(c, slots.data(), n, kps, desc, cap, n_out)
-                   : download_frames(c, slots.data(), n, kps, desc, cap, n_out);
+    rc = by_export ? export_frames(c, slots.data(), n, kps, desc, cap, n_out, view)
+                   : download_frames(c, slots.data(), n, kps, desc, cap, n_out, view);
     tr.mark("results");
     return rc;
+}
+} // namespace
+
+int slamfe_extract_batch(slamfe_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride,
+                         int channels, slamfe_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                         uint64_t* frame_handles)
+{
+    return extract_host_frames(c, imgs, n, w, h, stride, channels, kps, desc, cap, n_out, frame_handles, false);
+}
+
+int slamfe_extract_view(slamfe_ctx* c, const uint8_t* img, int w, int h, int stride, int channels,
+                        const slamfe_keypoint** kps, const uint8_t** desc, int* n_out, uint64_t* frame_handle)
+{
+    if (!c || !img || !kps || !desc || !n_out) return SLAMFE_E_INVALID;
+    *kps = nullptr;
+    *desc = nullptr;
+    *n_out = 0;
+    const uint8_t* one[1] = {img};
+    int n = 0;
+    int rc = extract_host_frames(c, one, 1, w, h, stride, channels, nullptr, nullptr, 0, &n, frame_handle, true);
+    *n_out = n;
+    if (rc) return rc;
+    // frame 0 of the pinned result arrays: records first, descriptor rows after
+    // the records of max_batch frames
+    *kps = reinterpret_cast<const slamfe_keypoint*>(c->h_out);
+    *desc = c->h_out + (size_t)c->p.max_batch * (size_t)c->max_kp * sizeof(slamfe_keypoint);
+    return SLAMFE_OK;
 }
 
 int slamfe_extract(slamfe_ctx* c, const uint8_t* img, int w, int h, int stride, int channels,
@@ -1079,22 +1109,29 @@ int slamfe_match_resident_batch(slamfe_ctx* c, uint64_t first_query, uint64_t fi
     return SLAMFE_OK;
 }
 
-int slamfe_match_frames(slamfe_ctx* c, uint64_t query_frame, uint64_t train_frame, slamfe_match2* out,
-                        int cap, int* nq_out)
+namespace {
+// Init.cc:131-153 on two resident frames with the rows brought to the host: copied
+// into out[0..cap), or (view != nullptr) left in the pinned bounce buffer for the
+// caller to read in place.
+int match_frames_to_host(slamfe_ctx* c, uint64_t query_frame, uint64_t train_frame, slamfe_match2* out,
+                         int cap, int* nq_out, const slamfe_match2** view)
 {
     if (!c) return SLAMFE_E_INVALID;
+    if (view) *view = nullptr;
     HIPCHK(c, hipSetDevice(c->p.device_id));
     const int sq = slot_of(c, query_frame);
     if (sq < 0 || slot_of(c, train_frame) < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown");
+    const bool rows = out || view;
     // The query frame's keypoint count is known on the host if the frame came
     // through a host-pointer call.  Then the rows are written by the merge kernel
     // straight into pinned host memory (which the device can address): one launch
     // sequence, one wait.
     int32_t nq = c->slot_count_host[(size_t)sq];
-    if (out && nq >= 0) {
+    if (nq >= 0) {
         if (nq > c->max_kp) nq = c->max_kp;
         if (nq_out) *nq_out = nq;
-        if (nq > cap)
+        if (!rows) return SLAMFE_OK; // only the count was asked for: nothing to launch
+        if (!view && nq > cap)
             return fail(c, SLAMFE_E_CAPACITY, "%d match rows exceed the caller's capacity %d", nq, cap);
         int rc = pin_reserve(c, (size_t)c->max_kp * sizeof *out);
         if (rc) return rc;
@@ -1102,30 +1139,50 @@ int slamfe_match_frames(slamfe_ctx* c, uint64_t query_frame, uint64_t train_fram
         if ((rc = slamfe_match_resident(c, query_frame, train_frame, reinterpret_cast<slamfe_match2*>(c->h_pin))))
             return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (nq > 0) memcpy(out, c->h_pin, (size_t)nq * sizeof *out);
+        if (view) *view = reinterpret_cast<const slamfe_match2*>(c->h_pin);
+        else if (nq > 0) memcpy(out, c->h_pin, (size_t)nq * sizeof *out);
         return SLAMFE_OK;
     }
-    int rc = slamfe_match_resident(c, query_frame, train_frame, c->match_out);
-    if (rc) return rc;
+    // count not known yet: read it back first (the rows are matched only if wanted)
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->kp_count + sq, sizeof(int32_t), hipMemcpyDeviceToHost,
                              c->stream));
+    if (rows) {
+        int rc = slamfe_match_resident(c, query_frame, train_frame, c->match_out);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     nq = c->h_cnt[0];
     c->slot_count_host[(size_t)sq] = nq;
     if (nq > c->max_kp) nq = c->max_kp;
     if (nq_out) *nq_out = nq;
-    if (out) {
-        if (nq > cap)
+    if (rows) {
+        if (!view && nq > cap)
             return fail(c, SLAMFE_E_CAPACITY, "%d match rows exceed the caller's capacity %d", nq, cap);
+        int rc = pin_reserve(c, (size_t)(nq > 0 ? nq : 1) * sizeof *out);
+        if (rc) return rc;
         if (nq > 0) {
-            if ((rc = pin_reserve(c, (size_t)nq * sizeof *out))) return rc;
             HIPCHK(c, hipMemcpyAsync(c->h_pin, c->match_out, (size_t)nq * sizeof *out,
                                      hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            memcpy(out, c->h_pin, (size_t)nq * sizeof *out);
         }
+        if (view) *view = reinterpret_cast<const slamfe_match2*>(c->h_pin);
+        else if (nq > 0) memcpy(out, c->h_pin, (size_t)nq * sizeof *out);
     }
     return SLAMFE_OK;
+}
+} // namespace
+
+int slamfe_match_frames(slamfe_ctx* c, uint64_t query_frame, uint64_t train_frame, slamfe_match2* out,
+                        int cap, int* nq_out)
+{
+    return match_frames_to_host(c, query_frame, train_frame, out, cap, nq_out, nullptr);
+}
+
+int slamfe_match_frames_view(slamfe_ctx* c, uint64_t query_frame, uint64_t train_frame,
+                             const slamfe_match2** rows, int* nq_out)
+{
+    if (!rows || !nq_out) return SLAMFE_E_INVALID;
+    return match_frames_to_host(c, query_frame, train_frame, nullptr, 0, nq_out, rows);
 }
 
 int slamfe_match_shard_keys(slamfe_ctx* c, const void* d_query, int nq, const void* d_train, int nt,

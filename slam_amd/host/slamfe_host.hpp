@@ -7,7 +7,9 @@
 //   Init.cc:64-66  detector / desc / matcher creation  -> slamfe::FrontEnd ctor
 //   Init.cc:74-79  Init::extractKeyPoints(frame, keypoints, descriptors)
 //                                                       -> FrontEnd::extractKeyPoints
-//   Init.cc:131    matcher->knnMatch(d1, d2, matches, 2) -> FrontEnd::knnMatch
+//   Init.cc:131    matcher->knnMatch(d1, d2, matches, 2) -> FrontEnd::knnMatch (on the two
+//                  frames' handles: both are on the device already; the descriptor
+//                  matrices need not travel again)
 //   Init.cc:229-259 the search-by-projection double loop -> FrontEnd::searchByProjection
 //   Init.cc:296    new Point(..., descriptors2.row(idx), ...) -> FrontEnd::mapPut
 //
@@ -23,6 +25,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -119,19 +122,17 @@ public:
 
     // Init::extractKeyPoints(frame, keypoints, descriptors), Init.cc:74-79.
     // Returns the handle of the device-resident copy of this frame's result.
+    // The library hands out its page-locked result arrays; exactly n records and
+    // n rows are copied from there (no buffers sized for the worst case, nothing
+    // value-initialised first).
     uint64_t extractKeyPoints(const ImageView& frame, std::vector<KeyPoint>& keypoints, Mat8& descriptors)
     {
-        keypoints.resize((size_t)capacity_);
-        descriptors.data.resize((size_t)capacity_ * 32);
+        const uint8_t* rows = nullptr;
         int n = 0;
-        uint64_t handle = 0;
-        check(slamfe_extract(ctx_, frame.data, frame.width, frame.height, frame.stride, frame.channels,
-                             reinterpret_cast<slamfe_keypoint*>(keypoints.data()), descriptors.data.data(),
-                             capacity_, &n, &handle));
-        keypoints.resize((size_t)n);
+        uint64_t handle = extractView(frame, keypoints, rows, n);
         descriptors.rows = n;
         descriptors.cols = 32;
-        descriptors.data.resize((size_t)n * 32);
+        descriptors.data.assign(rows, rows + (size_t)n * 32);
         return handle;
     }
 
@@ -144,20 +145,24 @@ public:
                               Mat8& descriptors)
     {
         if (frame.channels != 3) throw Error(SLAMFE_E_INVALID, "resizeAndExtract takes a BGR frame");
-        keypoints.resize((size_t)capacity_);
-        descriptors.data.resize((size_t)capacity_ * 32);
-        resized.resize((size_t)frame.width * frame.height * 3);
+        // staging arrays of the layer, allocated once and never initialised
+        if (!stageKps_) {
+            stageKps_.reset(new slamfe_keypoint[(size_t)capacity_]);
+            stageDesc_.reset(new uint8_t[(size_t)capacity_ * 32]);
+        }
+        if (resized.size() < (size_t)frame.width * frame.height * 3)
+            resized.resize((size_t)frame.width * frame.height * 3);
         int n = 0;
         uint64_t handle = 0;
         check(slamfe_extract_scaled_bgr(ctx_, frame.data, frame.width, frame.height, frame.stride, fx, fy,
-                                        resized.data(), &outWidth, &outHeight,
-                                        reinterpret_cast<slamfe_keypoint*>(keypoints.data()),
-                                        descriptors.data.data(), capacity_, &n, &handle));
+                                        resized.data(), &outWidth, &outHeight, stageKps_.get(),
+                                        stageDesc_.get(), capacity_, &n, &handle));
         resized.resize((size_t)outWidth * outHeight * 3);
-        keypoints.resize((size_t)n);
+        const KeyPoint* k = reinterpret_cast<const KeyPoint*>(stageKps_.get());
+        keypoints.assign(k, k + n);
         descriptors.rows = n;
         descriptors.cols = 32;
-        descriptors.data.resize((size_t)n * 32);
+        descriptors.data.assign(stageDesc_.get(), stageDesc_.get() + (size_t)n * 32);
         return handle;
     }
 
@@ -212,19 +217,54 @@ public:
         check(slamfe_triangulate(ctx_, P1, P2, pts1.data(), pts2.data(), n, xyz.data()));
     }
 
-    // matcher->knnMatch(descriptors1, descriptors2, matches, 2), Init.cc:131:
-    // matches[i] holds up to k = 2 DMatch in (distance, trainIdx) order.
-    void knnMatch(const Mat8& query, const Mat8& train, std::vector<std::vector<DMatch>>& matches, int k = 2)
+    // matcher->knnMatch(descriptors1, descriptors2, matches, 2), Init.cc:131, on the
+    // device-resident copies of the two frames (the handles extractKeyPoints
+    // returned for the previous and the current frame): nothing is uploaded.
+    // matches[i] holds up to k = 2 DMatch in (distance, trainIdx) order.  Inner
+    // vectors that matches already holds are reused, so a caller that does not
+    // clear it between frames pays no allocation after the first frame.
+    void knnMatch(uint64_t queryFrame, uint64_t trainFrame, std::vector<std::vector<DMatch>>& matches, int k = 2)
     {
         if (k != 2) throw Error(SLAMFE_E_INVALID, "only k = 2 is implemented (the reference's call)");
-        std::vector<slamfe_match2> rows((size_t)query.rows);
-        check(slamfe_match_knn2(ctx_, query.data.data(), query.rows, train.data.data(), train.rows, rows.data()));
-        matches.assign((size_t)query.rows, {});
-        for (int i = 0; i < query.rows; ++i) {
-            const slamfe_match2& m = rows[(size_t)i];
-            if (m.nfound > 0) matches[(size_t)i].push_back(make(i, m.idx0, m.d0));
-            if (m.nfound > 1) matches[(size_t)i].push_back(make(i, m.idx1, m.d1));
+        const slamfe_match2* rows = nullptr;
+        int nq = 0;
+        check(slamfe_match_frames_view(ctx_, queryFrame, trainFrame, &rows, &nq));
+        fillMatches(rows, nq, matches);
+    }
+
+    // Init.cc:131-153 in one step: knnMatch on the two frames' handles followed by
+    // the reference's ratio loop, which stops at the first query with fewer than two
+    // neighbours (Init.cc:145) and keeps matches[i][0] where
+    // matches[i][0].distance < 0.75f * matches[i][1].distance (Init.cc:146-147; the
+    // library evaluates the same float comparison with the context's ratio).  Fills
+    // goodMatches, pMatches1 and pMatches2 as Init.cc:148-151 do, without building
+    // the vector of vectors.  Returns the number of queries (matches.size()).
+    int knnMatchRatio(uint64_t queryFrame, uint64_t trainFrame, const std::vector<KeyPoint>& keypoints1,
+                      const std::vector<KeyPoint>& keypoints2, std::vector<DMatch>& goodMatches,
+                      std::vector<Point2f>& pMatches1, std::vector<Point2f>& pMatches2)
+    {
+        const slamfe_match2* rows = nullptr;
+        int nq = 0;
+        check(slamfe_match_frames_view(ctx_, queryFrame, trainFrame, &rows, &nq));
+        goodMatches.clear();
+        pMatches1.clear();
+        pMatches2.clear();
+        for (int i = 0; i < nq; ++i) {
+            const slamfe_match2& m = rows[i];
+            if (m.nfound < 2) break;
+            if (!m.ratio_pass) continue;
+            goodMatches.push_back(make(i, m.idx0, m.d0));
+            pMatches1.push_back(keypoints1[(size_t)i].pt);
+            pMatches2.push_back(keypoints2[(size_t)m.idx0].pt);
         }
+        return nq;
+    }
+
+    // The same call on descriptor matrices in host memory (both are uploaded): for
+    // descriptors that did not come from extractKeyPoints.
+    void knnMatch(const Mat8& query, const Mat8& train, std::vector<std::vector<DMatch>>& matches, int k = 2)
+    {
+        knnMatchHost(query.data.data(), query.rows, train.data.data(), train.rows, matches, k);
     }
 
     // new Point(id, ..., descriptors2.row(idx), ...), Init.cc:296: mirror the
@@ -261,23 +301,56 @@ public:
     {
         CV_Assert(frame.depth() == CV_8U && (frame.channels() == 1 || frame.channels() == 3));
         ImageView v{frame.data, frame.cols, frame.rows, (int)frame.step, frame.channels()};
-        Mat8 d;
-        uint64_t h = extractKeyPoints(v, keypoints, d);
-        descriptors.create(d.rows, 32, CV_8U); // fresh buffer: no aliasing with the previous frame
-        if (d.rows) std::memcpy(descriptors.data, d.data.data(), d.data.size());
+        const uint8_t* rows = nullptr;
+        int n = 0;
+        uint64_t h = extractView(v, keypoints, rows, n);
+        // a fresh buffer every frame: Mat::create alone would keep the old one when the
+        // keypoint count repeats, and descriptors1 / Point::desc still refer to it
+        // (Init.cc:296, Init.cc:323)
+        descriptors.release();
+        descriptors.create(n, 32, CV_8U);
+        if (n) std::memcpy(descriptors.data, rows, (size_t)n * 32);
         return h;
     }
     void knnMatch(const cv::Mat& query, const cv::Mat& train, std::vector<std::vector<cv::DMatch>>& matches, int k)
     {
         CV_Assert(query.isContinuous() && train.isContinuous() && query.cols == 32 && train.cols == 32);
-        Mat8 q, t;
-        q.rows = query.rows; q.cols = 32; q.data.assign(query.data, query.data + (size_t)query.rows * 32);
-        t.rows = train.rows; t.cols = 32; t.data.assign(train.data, train.data + (size_t)train.rows * 32);
-        knnMatch(q, t, matches, k);
+        knnMatchHost(query.data, query.rows, train.data, train.rows, matches, k);
     }
 #endif
 
 private:
+    // slamfe_extract_view + the copy of exactly n keypoint records
+    uint64_t extractView(const ImageView& frame, std::vector<KeyPoint>& keypoints, const uint8_t*& rows, int& n)
+    {
+        const slamfe_keypoint* kp = nullptr;
+        uint64_t handle = 0;
+        check(slamfe_extract_view(ctx_, frame.data, frame.width, frame.height, frame.stride, frame.channels, &kp,
+                                  &rows, &n, &handle));
+        const KeyPoint* k = reinterpret_cast<const KeyPoint*>(kp);
+        keypoints.assign(k, k + n);
+        return handle;
+    }
+    void knnMatchHost(const uint8_t* query, int nq, const uint8_t* train, int nt,
+                      std::vector<std::vector<DMatch>>& matches, int k)
+    {
+        if (k != 2) throw Error(SLAMFE_E_INVALID, "only k = 2 is implemented (the reference's call)");
+        matchRows_.resize((size_t)nq);
+        check(slamfe_match_knn2(ctx_, query, nq, train, nt, matchRows_.data()));
+        fillMatches(matchRows_.data(), nq, matches);
+    }
+    // rows -> vector<vector<DMatch>>; existing inner vectors keep their storage
+    static void fillMatches(const slamfe_match2* rows, int nq, std::vector<std::vector<DMatch>>& matches)
+    {
+        matches.resize((size_t)nq);
+        for (int i = 0; i < nq; ++i) {
+            const slamfe_match2& m = rows[i];
+            std::vector<DMatch>& v = matches[(size_t)i];
+            v.resize(m.nfound);
+            if (m.nfound > 0) v[0] = make(i, m.idx0, m.d0);
+            if (m.nfound > 1) v[1] = make(i, m.idx1, m.d1);
+        }
+    }
     static DMatch make(int q, int t, int d)
     {
         DMatch m;
@@ -293,6 +366,9 @@ private:
     }
     slamfe_ctx* ctx_ = nullptr;
     int capacity_ = 0;
+    std::unique_ptr<slamfe_keypoint[]> stageKps_;
+    std::unique_ptr<uint8_t[]> stageDesc_;
+    std::vector<slamfe_match2> matchRows_;
 };
 
 } // namespace slamfe

@@ -40,10 +40,21 @@ int main(int argc, char** argv)
         slamfe::FrontEnd fe(nfeatures, thold, W, H, SLAMFE_MODE_PROVIDED);
         std::vector<slamfe::KeyPoint> keypoints1, keypoints2;
         slamfe::Mat8 descriptors1, descriptors2;
-        fe.extractKeyPoints({fa.data(), W, H, W, 1}, keypoints1, descriptors1); // Init.cc:113
+        uint64_t h1 = fe.extractKeyPoints({fa.data(), W, H, W, 1}, keypoints1, descriptors1); // Init.cc:113
         uint64_t h2 = fe.extractKeyPoints({fb.data(), W, H, W, 1}, keypoints2, descriptors2); // Init.cc:130
-        std::vector<std::vector<slamfe::DMatch>> matches;
-        fe.knnMatch(descriptors1, descriptors2, matches, 2); // Init.cc:131
+        std::vector<std::vector<slamfe::DMatch>> matches, matchesHost;
+        fe.knnMatch(h1, h2, matches, 2); // Init.cc:131 on the resident frames
+        fe.knnMatch(descriptors1, descriptors2, matchesHost, 2); // ... and on host matrices: the same rows
+        REQUIRE(matches.size() == matchesHost.size());
+        for (size_t i = 0; i < matches.size(); ++i) {
+            REQUIRE(matches[i].size() == matchesHost[i].size());
+            REQUIRE(matches[i].empty() ||
+                    std::memcmp(matches[i].data(), matchesHost[i].data(), matches[i].size() * sizeof(slamfe::DMatch)) == 0);
+        }
+        // a second call into the same container reuses its inner vectors and gives the same rows
+        const slamfe::DMatch* inner0 = matches.empty() ? nullptr : matches[0].data();
+        fe.knnMatch(h1, h2, matches, 2);
+        REQUIRE(matches.empty() || matches[0].data() == inner0);
 
         // the checker on the same inputs
         slamfe_params p;
@@ -79,6 +90,17 @@ int main(int argc, char** argv)
             oracle_good += om[i].ratio_pass;
         }
         REQUIRE((int)goodMatches.size() == oracle_good && oracle_good > 50);
+        {   // Init.cc:131-153 in one step gives the same three vectors
+            std::vector<slamfe::DMatch> good2;
+            std::vector<slamfe::Point2f> p1, p2;
+            REQUIRE(fe.knnMatchRatio(h1, h2, keypoints1, keypoints2, good2, p1, p2) == n1);
+            REQUIRE(good2.size() == goodMatches.size() && p1.size() == good2.size() && p2.size() == good2.size());
+            for (size_t i = 0; i < good2.size(); ++i) {
+                REQUIRE(std::memcmp(&good2[i], &goodMatches[i], sizeof(slamfe::DMatch)) == 0);
+                REQUIRE(p1[i].x == keypoints1[(size_t)good2[i].queryIdx].pt.x && p1[i].y == keypoints1[(size_t)good2[i].queryIdx].pt.y);
+                REQUIRE(p2[i].x == keypoints2[(size_t)good2[i].trainIdx].pt.x && p2[i].y == keypoints2[(size_t)good2[i].trainIdx].pt.y);
+            }
+        }
 
         // a small map: every third good match becomes a map point made from
         // frame 2's descriptor row (Init.cc:296), projected near its keypoint

@@ -62,7 +62,7 @@ int main(int argc, char** argv)
 
         std::vector<slamfe::KeyPoint> keypoints1, keypoints2;
         slamfe::Mat8 descriptors1, descriptors2;
-        fe.extractKeyPoints({all.data(), W, H, W, 1}, keypoints1, descriptors1); // Init.cc:113
+        uint64_t h1 = fe.extractKeyPoints({all.data(), W, H, W, 1}, keypoints1, descriptors1); // Init.cc:113
         int on1 = orc_extract(&p, all.data(), W, H, W, 1, ORC_TRIG_CONTRACT, ok1.data(), od1.data(), cap);
         REQUIRE((int)keypoints1.size() == on1 && on1 > 50);
 
@@ -71,6 +71,7 @@ int main(int argc, char** argv)
         std::vector<float> mapXyz;
         std::vector<uint8_t> mapDesc;
         int npoints = 0, total_hits = 0, total_new = 0, total_good = 0;
+        std::vector<std::vector<slamfe::DMatch>> matches;
         for (fr = 1; fr < N; ++fr) {
             const uint8_t* img = all.data() + (size_t)fr * W * H;
             uint64_t h2 = fe.extractKeyPoints({img, W, H, W, 1}, keypoints2, descriptors2); // Init.cc:130
@@ -79,8 +80,7 @@ int main(int argc, char** argv)
             REQUIRE(std::memcmp(keypoints2.data(), ok2.data(), (size_t)on2 * sizeof(slamfe_keypoint)) == 0);
             REQUIRE(std::memcmp(descriptors2.data.data(), od2.data(), (size_t)on2 * 32) == 0);
 
-            std::vector<std::vector<slamfe::DMatch>> matches;
-            fe.knnMatch(descriptors1, descriptors2, matches, 2); // Init.cc:131
+            fe.knnMatch(h1, h2, matches, 2); // Init.cc:131 (matches is not cleared: its inner vectors are reused)
             std::vector<slamfe_match2> om((size_t)on1);
             orc_match_knn2(od1.data(), on1, od2.data(), on2, 0.75f, om.data());
             std::vector<slamfe::DMatch> goodMatches;
@@ -186,6 +186,7 @@ int main(int argc, char** argv)
 
             keypoints1 = keypoints2; // Init.cc:322-323
             descriptors1 = descriptors2;
+            h1 = h2;
             ok1 = ok2;
             od1 = od2;
             on1 = on2;

@@ -47,6 +47,7 @@ public:
     int channels() const;
     bool isContinuous() const;
     void create(int rows, int cols, int type);
+    void release();
     template <typename T> T* ptr(int row = 0);
     template <typename T> const T* ptr(int row = 0) const;
 };

@@ -36,10 +36,13 @@ def test_patch_applies_to_the_reference(tmp_path):
         assert gone not in cc, gone
     # ... and the host layer is called in their place
     for call in ("new slamfe::FrontEnd(nfeatures, thold", "fe->extractKeyPoints(frame, keypoints, descriptors)",
-                 "fe->knnMatch(descriptors1, descriptors2, matches, 2)", "fe->searchByProjection(frameHandle",
+                 "fe->knnMatch(frameHandle1, frameHandle2, matches, 2)", "fe->searchByProjection(frameHandle2",
+                 "frameHandle2 = fe->extractKeyPoints(", "descriptors1 = descriptors2;\n        frameHandle1 = frameHandle2;",
+                 "extractKeyPoints(frame, keypoints1, descriptors1);\n    frameHandle1 = frameHandle2;",
                  "fe->mapPut(pt->id, descriptors2.ptr<uchar>(idx))"):
         assert call in cc, call
     assert '#include "slamfe_host.hpp"' in h and "std::unique_ptr<slamfe::FrontEnd> fe;" in h
+    assert "uint64_t frameHandle1 = 0, frameHandle2 = 0;" in h
     assert "SLAMFE_WITH_OPENCV" in cm and "slamfe" in cm.split("target_link_libraries")[1]
     # everything the optimiser and the map read stays as it was
     for kept in ("optimizer.BundleAdjustment(m, 10, 0)", "keyframe->addKeypoint(keypoints2[idx], points[mPoint]->id)",
@@ -67,8 +70,13 @@ uint64_t use(slamfe::FrontEnd& fe, cv::Mat& frame, std::vector<cv::KeyPoint>& kp
              std::vector<std::vector<cv::DMatch>>& m, std::vector<cv::Point2f>& rPoints, std::vector<int>& ids,
              std::vector<int>& inl)
 {
+    uint64_t h0 = fe.extractKeyPoints(frame, kp, d2);
     uint64_t h = fe.extractKeyPoints(frame, kp, d1);
+    fe.knnMatch(h0, h, m, 2);
     fe.knnMatch(d1, d2, m, 2);
+    std::vector<cv::DMatch> good;
+    std::vector<cv::Point2f> p1, p2;
+    fe.knnMatchRatio(h0, h, kp, kp, good, p1, p2);
     std::vector<int> hit = fe.searchByProjection(h, inl, rPoints, ids);
     fe.mapPut(3, d2.ptr<cv::uchar>(0));
     return h + hit.size();
