@@ -351,7 +351,11 @@ int slamfe_frame_device_ptrs(slamfe_ctx* ctx, uint64_t frame_handle, const slamf
  * most recent extraction of `nframes` frames `reps` times on the context's
  * stream, bracketed by HIP events on that stream, and return the average
  * milliseconds per repetition.  Every stage is idempotent on the resident
- * data, so the frame results are unchanged afterwards. */
+ * data, so the frame results are unchanged afterwards.  Gray device frames whose
+ * rows have level 0's pitch (width a multiple of 64, rows and frames 16-byte
+ * aligned) are read in place by slamfe_extract_resident, not copied: the stages
+ * that read level 0 (1, 2, 4) and slamfe_debug_read_level(level 0) read the
+ * caller's frames again, which must therefore still be allocated and unchanged. */
 #define SLAMFE_STAGE_PYRAMID 1
 #define SLAMFE_STAGE_FAST 2 /* fused FAST + NMS + blur kernel */
 #define SLAMFE_STAGE_SELECT 3

@@ -159,7 +159,12 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
         // the tap table is padded with zero entries to a multiple of 4 per level
         const uint4 tx = *reinterpret_cast<const uint4*>(taps + D.tap_x + x);
         const uint32_t txs[4] = {tx.x, tx.y, tx.z, tx.w};
-        const uint32_t a = (txs[0] & 0xffffu) & ~3u; // aligned start of the 12 source bytes
+        // aligned start of the 12 source bytes, kept inside the row: a window that would
+        // run past the row's last byte starts earlier instead (the taps that matter
+        // end at column w - 1, so they stay inside the shifted window; a clamped tap's
+        // second byte may fall outside it and carries weight 0).  Level 1 may read
+        // the caller's frames in place, where nothing follows the last row.
+        const uint32_t a = min((txs[0] & 0xffffu) & ~3u, (uint32_t)S.pitch - 12u);
         // per pixel: which dword pair of the 12-byte window holds its two taps
         // (bytes o, o+1 with o = 0 .. 10: the pair (p0,p1) up to o = 6, else (p1,p2))
         // and the v_perm selector that picks them widened to 16 bits each

@@ -420,8 +420,10 @@ __global__ __launch_bounds__(256) void k_proj_resolve(
             int pos = 0, result = -1;
             bool done = lane >= nc;
             // every round finishes at least the first open lane, so 64 rounds always
-            // suffice; the bound makes the exit unconditional
-            while (__ballot(!done) && round < 2 * PROJ_CHUNK) {
+            // suffice; the bound makes the exit unconditional and keeps the round
+            // number inside its 7-bit field of the claim key
+            static_assert(PROJ_CHUNK + 1 < 128, "the claim key holds the round number in 7 bits");
+            while (__ballot(!done) && round < 127) {
                 int prop = -1; // position j of the proposed point
                 bool dry = false;
                 if (!done) {

@@ -296,6 +296,36 @@ def test_extract_frames_usable_in_place(nlevels, scale, nframes):
         assert sum(len(k) for k, _ in want) > 100
 
 
+def test_extract_in_place_from_a_buffer_with_nothing_behind_it():
+    # frames read in place from a device buffer of exactly n * w * h bytes taken straight
+    # from hipMalloc (no allocator padding behind the last row; 640 x 480 frames are whole
+    # 4 KiB pages): no kernel may read past the last byte of the last frame.  The level-1
+    # resize loads 12-byte windows and used to run 8 bytes over the end of every row.
+    import ctypes as C
+    from slam_amd.frontend import FrontEnd
+    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    w, h, n = 640, 480, 9
+    frames = np.ascontiguousarray(synth.frame_stream(w, h, n, seed=77))
+    assert frames.nbytes == n * w * h and frames.nbytes % 4096 == 0
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=1000, max_width=w, max_height=h,
+                  max_batch=n, map_capacity=0) as fe:
+        want = [O.extract(oracle_params(fe), fr) for fr in frames]
+        d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), frames.nbytes) == 0
+        try:
+            assert hip.hipMemcpy(d, frames.ctypes.data, frames.nbytes, 1) == 0  # host to device
+            handles = fe.extract_resident(d.value, n, w, h, w, w * h, 1)
+            fe.sync()
+            for hd, (kps, desc) in zip(handles, want):
+                assert_frame_equal(fe.frame_download(int(hd)), kps, desc)
+        finally:
+            fe.sync()
+            hip.hipFree(d)
+
+
 @pytest.mark.parametrize("kernel", [abi.MATCH_POPCOUNT, abi.MATCH_MATRIX])
 def test_match_extreme_descriptors_among_random_ones(kernel):
     # all-zero and all-one rows among random ones: distances 0 and 256 and queries of

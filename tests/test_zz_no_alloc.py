@@ -58,6 +58,33 @@ def test_static_scratch_keys_equal_growable_buffer_keys(kernel):
         fe.match_shard_keys_static(0, 0, dt.data_ptr(), 10, 0, dq.data_ptr())
 
 
+def test_static_entry_point_allocates_no_device_memory():
+    """The property the entry point exists for: device memory in use does not change over
+    its calls, on a context whose growable partial-result buffer has never been sized (a
+    call routed through that buffer would have to allocate here).  The job is the
+    relocalisation one, 2000 x 1,000,000, whose partials (3.9 MiB) nearly fill the array;
+    its keys are compared with the growable entry point's afterwards."""
+    import torch
+    from slam_amd.frontend import FrontEnd
+    nq, nt = 2000, 1_000_000
+    q, t = synth.descriptor_sets(nq, nt, seed=53, dup_percent=1)
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    keys = torch.full((nq, 2), -7, dtype=torch.int64, device="cuda")
+    keys_small = torch.full((nq, 2), -7, dtype=torch.int64, device="cuda")
+    with FrontEnd(mode=abi.MODE_ORB, max_width=64, max_height=64, max_batch=1, map_capacity=0,
+                  max_keypoints=64) as fe:
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info()
+        fe.match_shard_keys_static(dq.data_ptr(), nq, dt.data_ptr(), nt, 0, keys.data_ptr())
+        fe.match_shard_keys_static(dq.data_ptr(), 333, dt.data_ptr(), 70_001, 9, keys_small.data_ptr())
+        fe.sync()
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after == free_before, (free_before, free_after)
+        got, got_small = keys.cpu().numpy(), keys_small.cpu().numpy()[:333]
+        assert np.array_equal(got, _keys(fe, fe.match_shard_keys, dq, nq, dt, nt, 0))
+        assert np.array_equal(got_small, _keys(fe, fe.match_shard_keys, dq, 333, dt, 70_001, 9))
+
+
 def test_static_scratch_against_the_cpu_checker():
     import torch
     import oracle_lib as O
