@@ -177,12 +177,32 @@ def hbm_copy_ceiling(dev, nbytes=1 << 30, reps=10):
 
 def pmc_profile():
     """Counter readings of the committed rocprofv3 --pmc passes (they cannot be
-    collected inside this process)."""
+    collected inside this process), with their provenance: `source` names the file
+    and the commit they were measured on, `binary_matches` says whether the library
+    loaded by this run is byte for byte the one the counters were collected on
+    (tools/update_pmc_traffic.py records its SHA-256).  A mismatch is reported on
+    standard error: the counters then describe other kernels than the ones timed."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(tpath))
+        prof = json.load(open(tpath))
     except Exception:
         return {}
+    on = prof.get("measured_on", {})
+    prof["source"] = "profiles/pmc_traffic.json @ " + on.get("commit", "unknown commit")
+    want = on.get("libslamfe_sha256")
+    try:
+        import hashlib
+        from slam_amd._lib import LIB_PATH
+        have = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()
+    except Exception:
+        have = None
+    prof["binary_matches"] = bool(want) and want == have
+    if not prof["binary_matches"]:
+        print(f"bench.py: warning: the counters in {tpath} were collected on another build of libslamfe.so "
+              f"(recorded {str(want)[:12]}, loaded {str(have)[:12]}); roofline.traffic and limiter.wave_insts_per_launch "
+              "are not of the kernels timed here -- re-run tools/collect_profiles.sh and tools/update_pmc_traffic.py",
+              file=sys.stderr)
+    return prof
 
 
 def hbm_roofline(kernel, alg_bytes, ms, extra=None):
@@ -681,6 +701,7 @@ def main():
     if traffic is not None:
         # measured on launches of prof["frames_per_launch"] frames; per frame-proportional
         roofline["traffic"] = int(traffic * B / prof.get("frames_per_launch", B))
+        roofline["traffic_source"] = {"source": prof.get("source"), "binary_matches": prof.get("binary_matches")}
     winsts = prof.get(hbm_stage + "_wave_insts")
     if winsts is not None:
         # What actually bounds the kernel: vector-instruction issue.  One wave
@@ -690,7 +711,11 @@ def main():
         issue_ms = winsts / VALU_ISSUE_PER_S * 1e3
         roofline["limiter"] = {"bound": "vector instruction issue", "wave_insts_per_launch": int(winsts),
                                "peak_wave_insts_per_s": VALU_ISSUE_PER_S, "issue_time_ms": round(issue_ms, 5),
-                               "frac": round(issue_ms / stage_ms[hbm_stage], 4)}
+                               "frac": round(issue_ms / stage_ms[hbm_stage], 4),
+                               "source": prof.get("source"), "binary_matches": prof.get("binary_matches")}
+        minsts = prof.get(hbm_stage + "_mfma_insts")
+        if minsts is not None:
+            roofline["limiter"]["mfma_insts_per_launch"] = int(minsts * B / prof.get("frames_per_launch", B))
 
     # Hamming comparisons/s of the match kernel inside the frame pipeline
     # (a step matches B pairs in one call: frame i with frame i-1, frame 0 with

@@ -516,9 +516,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyramid_fused(slamfe_dev_geom g,
 //         pass D: NMS of list entries against the LDS score tile; keypoints
 //                 inside the ORB border go to the tile's candidate list and to
 //                 the level's score histogram
-//  blur   rows:   v_dot4_u32_u8 of byte windows cut out with v_alignbyte
-//                 (3.5 VALU ops per output), 16-bit sums to LDS, two rows per word
-//         cols:   v_dot2_u32_u16 per pair of taps, round, saturate, 4 pixels per store
+//  blur   on the matrix cores (blur_mfma below): the separable 7-tap filter is
+//         a product with a banded matrix of taps on either side, exact in i32
 // ---------------------------------------------------------------------------
 #define FL_W (TW + 32)         /* LDS tile row: image columns x0-16 .. x0+79, six 16-byte pieces */
 #define FL_WD (FL_W / 4)
@@ -530,7 +529,164 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyramid_fused(slamfe_dev_geom g,
 #define FS_W (TW + 2)          /* score tile: 66 x (GH + 2) */
 #define FS_H (GH + 2)
 #define FS_N (FS_W * FS_H)
-#define BR_H (GH + 6)          /* rows of blur row sums */
+
+// ---------------------------------------------------------------------------
+// The 7x7 blur as two chained matrix products (v_mfma_i32_32x32x32_i8).
+//
+// With P the LDS tile, T the band matrix of the taps k = [18,34,49,55,49,34,18]:
+//   row pass     S[r][x] = sum_c P[r][c] * k[c - x + 3]           (S = P * T)
+//   column pass  F[x][y] = sum_r S[r][x] * k[r - y + 3]           (F = S^T * T)
+//   out[y][x]    = min((F + 2^15) >> 16, 255)
+// All sums are exact integers, so any exact decomposition gives the filter's
+// bytes.  One wave produces 32 columns x 32 rows of output:
+//
+//  * row pass: A = pixels, lane = tile row r (two blocks of 32 rows: the 38 rows
+//    an output block needs), 16 consecutive bytes of the row per lane and k-step
+//    (one ds_read_b128; two k-steps cover the 38 columns); B = taps, constant per
+//    lane.  The instruction multiplies signed bytes: pixels are re-centred to
+//    p - 128 (p ^ 0x80), which shifts every row sum by 128 * 257.
+//  * the result tile has its column x on the lane and its rows in the 16
+//    registers, which is the operand layout of a product that sums over rows:
+//    the column pass takes it as its A operand with no lane movement.  A row sum
+//    needs 16 bits, an operand byte holds 8: D + 128 (range -32768 .. 32767) is
+//    split into its signed high byte h and its low byte, taken as l - 128, so
+//    D = 256 h + (l - 128) and F = 256 * sum k h + sum k (l - 128) + constants:
+//    two accumulator chains, joined by one shift-and-add per output.
+//  * constants ride in operand bytes the filter does not use: tile columns 0 and
+//    95 hold 0x82 (2 after re-centring) against a tap-matrix entry of 64 -- the
+//    "+ 128" of the split; in the second k-step of the column pass (tile rows
+//    33 .. 64, of which only 33 .. 38 exist) four operand bytes are constants
+//    against entries of 64, which adds 128 * 257 * 257 + 2^15 (the re-centring
+//    undone, the split's offsets, the rounding constant) to F.
+//  * the column pass leaves the output row y on the lane and four consecutive
+//    columns in registers 4q .. 4q+3: one dword store per q into the tiled
+//    blurred level.
+// ---------------------------------------------------------------------------
+typedef int blur_v4i __attribute__((ext_vector_type(4)));
+typedef int blur_v16i __attribute__((ext_vector_type(16)));
+
+// tile row of element j of lane half h in a result tile used as an operand
+constexpr int blur_rho(int h, int j) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+constexpr int blur_tap(int t)
+{
+    constexpr int K[7] = SLAMFE_GAUSS7_INIT;
+    return t >= 0 && t <= 6 ? K[t] : 0;
+}
+// Tap operands, per lane (n = lane & 31, h = lane >> 5), 16 bytes each:
+//  b1[xb][s]: row pass, k-step s; byte j belongs to the tile column 16 + 32 xb
+//             - 16 + 32 s + 16 h + j and weighs into output column 16 + 32 xb + n
+//  b2[mb]:    column pass, k-step mb; byte j belongs to tile row 1 + 32 mb +
+//             rho(h, j) and weighs into output row 4 + n
+struct slamfe_blur_tab {
+    uint32_t b1[2][2][64][4];
+    uint32_t b2[2][64][4];
+};
+constexpr slamfe_blur_tab make_blur_tab()
+{
+    slamfe_blur_tab T{};
+    for (int lane = 0; lane < 64; ++lane) {
+        const int n = lane & 31, h = lane >> 5;
+        for (int j = 0; j < 16; ++j) {
+            for (int xb = 0; xb < 2; ++xb)
+                for (int s = 0; s < 2; ++s) {
+                    int v = blur_tap(-16 + 32 * s + 16 * h + j - n + 3);
+                    // the constant column (tile column 0 for xb = 0, 95 for xb = 1)
+                    if ((xb == 0 && s == 0 && h == 0 && j == 0) || (xb == 1 && s == 1 && h == 1 && j == 15)) v += 64;
+                    T.b1[xb][s][lane][j >> 2] |= (uint32_t)v << (8 * (j & 3));
+                }
+            for (int mb = 0; mb < 2; ++mb) {
+                int v = blur_tap(32 * mb + blur_rho(h, j) - n);
+                if (mb == 1 && j >= 4 && j < 8) v += 64; // against the constant operand bytes
+                T.b2[mb][lane][j >> 2] |= (uint32_t)v << (8 * (j & 3));
+            }
+        }
+    }
+    return T;
+}
+__device__ const slamfe_blur_tab g_blur_tab = make_blur_tab();
+// constant operand bytes 4 .. 7 of the column pass's second k-step, both lane
+// halves: 2 * 64 * (256 * (127 + 127 + 5) + 1) = 128 * 257 * 257 + 2^15
+#define BLUR_CONST_H 0x00057f7fu
+#define BLUR_CONST_L 0x00000001u
+static_assert(2 * 64 * (256 * (127 + 127 + 5) + 1) == 128 * 257 * 257 + (1 << 15), "blur constants");
+
+__device__ __forceinline__ void blur_mfma(const uint32_t* tile32, int xb, int lane, int nrows, int x0,
+                                          int y0, int w, int pitch, uint8_t* __restrict__ out_level)
+{
+    const int n = lane & 31, h = lane >> 5;
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile32);
+    auto tab = [&](const uint32_t* p) { return *reinterpret_cast<const blur_v4i*>(p); };
+    const blur_v4i b1s0 = tab(g_blur_tab.b1[xb][0][lane]), b1s1 = tab(g_blur_tab.b1[xb][1][lane]);
+    const blur_v4i b2k0 = tab(g_blur_tab.b2[0][lane]), b2k1 = tab(g_blur_tab.b2[1][lane]);
+    // ---- row pass: tile rows 1 .. 32 and 33 .. 38 (lanes past row 38 read the last row)
+    const int colb = 32 * xb + 16 * h;
+    const uint8_t* r0 = tb + (1 + n) * FL_W + colb;
+    const uint8_t* r1 = tb + min(33 + n, FL_H - 1) * FL_W + colb;
+    auto pix = [&](const uint8_t* p) {
+        blur_v4i a = *reinterpret_cast<const blur_v4i*>(p);
+        a ^= (int)0x80808080u;
+        return a;
+    };
+    blur_v16i d0 = {0}, d1 = {0};
+    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(pix(r0), b1s0, d0, 0, 0, 0);
+    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(pix(r0 + 32), b1s1, d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(pix(r1), b1s0, d1, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(pix(r1 + 32), b1s1, d1, 0, 0, 0);
+    // ---- split: registers 4q .. 4q+3 -> one dword of high bytes, one of (low byte - 128)
+    auto split = [&](const blur_v16i& d, int q, int& hi, int& lo) {
+        const uint32_t t0 = __builtin_amdgcn_perm((uint32_t)d[4 * q + 1], (uint32_t)d[4 * q], 0x05010400u);
+        const uint32_t t1 = __builtin_amdgcn_perm((uint32_t)d[4 * q + 3], (uint32_t)d[4 * q + 2], 0x05010400u);
+        lo = (int)(__builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u);
+        hi = (int)__builtin_amdgcn_perm(t1, t0, 0x07060302u);
+    };
+    blur_v4i aH0, aL0, aH1, aL1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int hi, lo;
+        split(d0, q, hi, lo);
+        aH0[q] = hi;
+        aL0[q] = lo;
+    }
+    {
+        int hi, lo;
+        split(d1, 0, hi, lo); // tile rows 33 .. 40: all that exist of the second block
+        aH1 = blur_v4i{hi, (int)BLUR_CONST_H, 0, 0};
+        aL1 = blur_v4i{lo, (int)BLUR_CONST_L, 0, 0};
+    }
+    // ---- column pass
+    blur_v16i fh = {0}, fl = {0};
+    fh = __builtin_amdgcn_mfma_i32_32x32x32_i8(aH0, b2k0, fh, 0, 0, 0);
+    fh = __builtin_amdgcn_mfma_i32_32x32x32_i8(aH1, b2k1, fh, 0, 0, 0);
+    fl = __builtin_amdgcn_mfma_i32_32x32x32_i8(aL0, b2k0, fl, 0, 0, 0);
+    fl = __builtin_amdgcn_mfma_i32_32x32x32_i8(aL1, b2k1, fl, 0, 0, 0);
+    // ---- join, round (the constant is in), saturate, store: lane = output row
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    union pk { uint32_t u; us2 v; };
+    const int gy = y0 + n;
+    // The blurred level is stored in tiles of 16 x 8 pixels (one 128-byte line
+    // each, tiles row-major): the descriptor kernel fetches a keypoint's
+    // neighbourhood as whole lines.  Rows are padded to a multiple of 64 bytes,
+    // so a store that covers pixels beyond w stays inside the level.
+    // (a level is far below 4 GiB: 32-bit offsets from the level's uniform base)
+    const uint32_t orow = (uint32_t)(gy >> 3) * (uint32_t)(pitch >> 4) * 128u + (uint32_t)(gy & 7) * 16u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = ((uint32_t)fh[4 * q + i] << 8) + (uint32_t)fl[4 * q + i];
+        // t >> 16 is at most 257: two of them per dword as 16-bit values, clamped together
+        pk p01, p23, lim;
+        lim.u = 0x00ff00ffu;
+        p01.u = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u);
+        p23.u = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u);
+        p01.v = __builtin_elementwise_min(p01.v, lim.v);
+        p23.v = __builtin_elementwise_min(p23.v, lim.v);
+        const uint32_t px = __builtin_amdgcn_perm(p23.u, p01.u, 0x06040200u);
+        const int gx = x0 + 32 * xb + 8 * q + 4 * h;
+        if (n < nrows && gx < w)
+            *reinterpret_cast<uint32_t*>(out_level + (orow + (uint32_t)(gx >> 4) * 128u + (uint32_t)(gx & 15))) = px;
+    }
+}
 
 // atomicAdd on an LDS word, written as the instruction itself: the compiler
 // rewrites atomicAdd into a scan over the lanes (per-lane operands) or a
@@ -583,7 +739,6 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
 {
     __shared__ uint32_t tile32[FL_H * FL_WD];
     __shared__ uint32_t sc32[(FS_N + 3) / 4];
-    __shared__ uint32_t rows32[(BR_H + 1) / 2 * TW];
     __shared__ uint16_t pos[FS_N];
     __shared__ uint32_t list[SLAMFE_FB_TILES * SLAMFE_TILE_CAND];
     __shared__ uint32_t nlist[SLAMFE_FB_TILES], npos;
@@ -613,6 +768,10 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         uint4 v = make_uint4(0, 0, 0, 0);
         if (gx >= 0 && gx < L.pitch)
             v = *reinterpret_cast<const uint4*>(img + (size_t)gy * L.pitch + gx);
+        // tile columns 0 and 95 (image columns x0-16 and x0+79, which nothing reads
+        // as pixels) carry the constant 0x82 of the matrix-core blur
+        if (pc == 0) v.x = (v.x & 0xffffff00u) | 0x82u;
+        if (pc == 5) v.w = (v.w & 0x00ffffffu) | 0x82000000u;
         *reinterpret_cast<uint4*>(&tile32[ly * FL_WD + 4 * pc]) = v;
     }
     for (int i = tid; i < ((nrows + 2) * FS_W + 3) / 4; i += 256) sc32[i] = 0;
@@ -688,7 +847,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             return __builtin_amdgcn_perm(neg[1], neg[0], 0x07030501u);
         };
         // (the tasks past the first 256 go to the last wave, which takes no part
-        // in the blur row pass below)
+        // in the blur below)
         for (int i = tid, it = 0; any_fast && it < 2; ++it, i = 256 + ((tid + 64) & 255)) {
             if (i >= (nrows + 2) * (FB_COLD / 2)) continue;
             int sy = i / (FB_COLD / 2), m = i - sy * (FB_COLD / 2);
@@ -750,37 +909,12 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         }
     }
 
-    // ---- blur row pass: task = (row pair j, dword c of 16) -> the 4 row sums of
-    // sum rows 2j and 2j+1 (tile rows 2j+1, 2j+2), stored as pairs
-    // (row 2j | row 2j+1 << 16) per column: the column pass then feeds both
-    // halves of v_dot2_u32_u16 with real data
-    {
-        const uint32_t KA = 18u | (34u << 8) | (49u << 16) | (55u << 24); // taps 0..3
-        const uint32_t KB = 49u | (34u << 8) | (18u << 16);               // taps 4..6, 0
-        // the 4 sums of the dword whose window is (d0, d1, d2): output j reads
-        // bytes (j+1 .. j+7) of the 12-byte window; each sum is <= 257 * 255 = 65535
-        auto rows4 = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t* o) {
-            uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA, 0, false);
-            o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, s0, false);
-            uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA, 0, false);
-            o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, s1, false);
-            uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA, 0, false);
-            o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, s2, false);
-            uint32_t s3 = __builtin_amdgcn_udot4(d1, KA, 0, false);
-            o[3] = __builtin_amdgcn_udot4(d2, KB, s3, false);
-        };
-        // (the last wave has the pretest's remainder: the row pass is shared by
-        // the other three)
-        for (int i = tid; tid < 192 && i < ((nrows + 7) >> 1) * 16; i += 192) {
-            int j = i >> 4, c = i & 15;
-            const uint32_t* p = &tile32[(2 * j + 1) * FL_WD + FL_X0 / 4 + c]; // columns x0-4+4c .. +11
-            uint32_t a[4], b[4];
-            rows4(p[0], p[1], p[2], a);
-            rows4(p[FL_WD], p[FL_WD + 1], p[FL_WD + 2], b);
-            *reinterpret_cast<uint4*>(&rows32[j * TW + 4 * c]) =
-                make_uint4(a[0] | (b[0] << 16), a[1] | (b[1] << 16), a[2] | (b[2] << 16), a[3] | (b[3] << 16));
-        }
-    }
+    // ---- blur: waves 0 and 1 each produce 32 columns x nrows rows on the matrix
+    // cores (the pretest's remainder above went to wave 3); the blur reads only the
+    // tile, so nothing waits for it
+    if (tid < 128) // uniform per wave
+        blur_mfma(tile32, tid >> 6, tid & 63, nrows, x0, y0, L.w, L.pitch,
+                  blur + (size_t)f * g.frame_bytes + L.off);
     __syncthreads();
 
     // ---- FAST pass C: full score of the pretest survivors
@@ -791,54 +925,6 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         sc[i] = (uint8_t)fast_score_lds(&tile[(sy + 3) * FL_W + FL_X0 + sx + 3], thr);
     }
 
-    // ---- blur column pass: task = (output row pair q, group k of 16) -> 2 x 4
-    // pixels.  Output row 2q sums rows 2q .. 2q+6 = pairs q .. q+3 with taps
-    // (K0,K1)(K2,K3)(K4,K5)(K6,0); row 2q+1 the same pairs with (0,K0)(K1,K2)(K3,K4)(K5,K6).
-    for (int task = tid; task < ((nrows + 1) >> 1) * 16; task += 256) {
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        union pk { uint32_t u; us2 v; };
-        constexpr uint32_t K[7] = SLAMFE_GAUSS7_INIT;
-        constexpr uint32_t TE[4] = {K[0] | (K[1] << 16), K[2] | (K[3] << 16), K[4] | (K[5] << 16), K[6]};
-        constexpr uint32_t TO[4] = {K[0] << 16, K[1] | (K[2] << 16), K[3] | (K[4] << 16), K[5] | (K[6] << 16)};
-        int q = task >> 4, k = task & 15;
-        int gy = y0 + 2 * q, gx = x0 + 4 * k;
-        if (gx < L.w) {
-            // the accumulators start at the rounding constant of the final >> 16
-            uint32_t e[4] = {32768u, 32768u, 32768u, 32768u}, o[4] = {32768u, 32768u, 32768u, 32768u};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint4 v = *reinterpret_cast<const uint4*>(&rows32[(q + i) * TW + 4 * k]);
-                const uint32_t col[4] = {v.x, v.y, v.z, v.w};
-                pk te, to;
-                te.u = TE[i];
-                to.u = TO[i];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    pk d;
-                    d.u = col[c];
-                    e[c] = __builtin_amdgcn_udot2(d.v, te.v, e[c], false);
-                    o[c] = __builtin_amdgcn_udot2(d.v, to.v, o[c], false);
-                }
-            }
-            // result = min(acc >> 16, 255) = byte 2 of min(acc, 0x00ffffff)
-            auto pack = [](const uint32_t* a) -> uint32_t {
-                uint32_t a0 = min(a[0], 0x00ffffffu), a1 = min(a[1], 0x00ffffffu);
-                uint32_t a2 = min(a[2], 0x00ffffffu), a3 = min(a[3], 0x00ffffffu);
-                uint32_t lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);
-                uint32_t hi = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
-                return lo | hi;
-            };
-            // The blurred level is stored in tiles of 16 x 8 pixels (one 128-byte line
-            // each, tiles row-major): the descriptor kernel fetches a keypoint's
-            // neighbourhood as whole lines.  gy is even, so both rows lie in one tile;
-            // rows are padded to a multiple of 64 bytes and the level to a multiple
-            // of 8 rows, so stores that cover pixels beyond w stay inside the level.
-            uint8_t* out = blur + (size_t)f * g.frame_bytes + L.off +
-                           ((size_t)(gy >> 3) * (size_t)(L.pitch >> 4) + (size_t)(gx >> 4)) * 128 + (gy & 7) * 16 + (gx & 15);
-            *reinterpret_cast<uint32_t*>(out) = pack(e);
-            if (gy + 1 < L.h) *reinterpret_cast<uint32_t*>(out + 16) = pack(o);
-        }
-    }
     __syncthreads();
 
     // ---- FAST pass D: NMS of the survivors, border filter, emission

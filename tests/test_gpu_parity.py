@@ -67,6 +67,33 @@ def test_pyramid_ragged_sizes(fe_orb, shape):
         assert np.array_equal(fe_orb.debug_read_level(0, l, True), O.blur7(want))
 
 
+@pytest.mark.parametrize("kind", ["white", "black", "binary", "checker", "noise", "steps"])
+def test_blur_extreme_images(fe_orb, kind):
+    # the ends of the blur's integer range: the tap sum is 257, so an all-white
+    # neighbourhood gives (257 * 257 * 255 + 2^15) >> 16 = 257 and must saturate to 255;
+    # black / white patterns drive every row sum and its 8-bit halves (the blur splits a
+    # row sum into a high and a low byte for the matrix cores) to their extremes
+    w, h = 335, 251  # ragged: partial tiles on both edges, a last tile group of few rows
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = {
+        "white": np.full((h, w), 255, np.uint8),
+        "black": np.zeros((h, w), np.uint8),
+        "binary": (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8),
+        "checker": (((xx // 3 + yy // 5) & 1) * 255).astype(np.uint8),
+        "noise": rng.integers(0, 256, (h, w), dtype=np.uint8),
+        "steps": np.where(xx < w // 2, 254, 255).astype(np.uint8) - (yy % 2).astype(np.uint8),
+    }[kind]
+    from slam_amd.frontend import SlamfeError
+    try:
+        fe_orb.extract_keypoints(img)
+    except SlamfeError as e:  # thousands of tied corners on the patterns: the levels are made all the same
+        assert e.code == abi.SLAMFE_E_CAPACITY
+    for l, want in enumerate(O.build_pyramid(img)):
+        assert np.array_equal(fe_orb.debug_read_level(0, l, False), want), (kind, l)
+        assert np.array_equal(fe_orb.debug_read_level(0, l, True), O.blur7(want)), (kind, l)
+
+
 # --------------------------------------------------------------- extraction
 def test_extract_orb_640x480_pair(fe_orb):
     a, b = synth.frame_pair(640, 480)
@@ -303,7 +330,10 @@ def test_extract_in_place_from_a_buffer_with_nothing_behind_it():
     # resize loads 12-byte windows and used to run 8 bytes over the end of every row.
     import ctypes as C
     from slam_amd.frontend import FrontEnd
-    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so.7")
+    import torch  # noqa: F401  (the process's HIP runtime is the one torch brought in)
+    with open("/proc/self/maps") as maps:
+        hip_path = next(line.split()[-1] for line in maps if "libamdhip64" in line)
+    hip = C.CDLL(hip_path)  # the runtime already loaded, not a second copy
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipFree.argtypes = [C.c_void_p]
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
