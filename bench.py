@@ -442,6 +442,39 @@ def leg_config2(local_rank, check):
             assert rc == 0, rc
         t_proj = timed(search, 30, fe.sync)
         got = matched.copy()
+        # The same search fed by the device-side reprojection (Init.cc:203-218), as the
+        # patched loop runs it: slamfe_reproject leaves the visible set on the device and
+        # queues the search grid behind it; the search call is candidates + resolve.
+        pose, Kc, xyz, th = synth.scene_from_uv(uv, w, h)
+        fe.map_put_xyz(ids, xyz)
+        nvis = C.c_int32()
+        pose_c, K_c = np.ascontiguousarray(pose), np.ascontiguousarray(Kc)
+        matched_v = np.zeros(len(inl), np.int32)
+
+        def reproj():
+            rc = fe._lib.slamfe_reproject(fe._ctx, pose_c.ctypes.data, K_c.ctypes.data, C.c_float(th),
+                                          C.c_float(w), C.c_float(h), npts, None, None, 0, C.byref(nvis))
+            assert rc == 0, rc
+
+        def search_vis():
+            rc = fe._lib.slamfe_search_by_projection_visible(fe._ctx, C.c_uint64(f1.handle), inl.ctypes.data,
+                                                             len(inl), C.c_float(32.0), 128, matched_v.ctypes.data)
+            assert rc == 0, rc
+        for _ in range(5):
+            reproj()
+            search_vis()
+        tr, tv = [], []
+        for _ in range(40):
+            a = time.perf_counter()
+            reproj()
+            b = time.perf_counter()
+            search_vis()
+            tv.append(time.perf_counter() - b)
+            tr.append(b - a)
+        t_reproj, t_vis = float(np.median(tr)), float(np.median(tv))
+        vis_uv, vis_idx = fe.reproject(pose, Kc, th, w, h, npts)
+        search_vis()
+        got_v = matched_v.copy()
     alg = algorithmic_bytes_per_frame(w, h)["fast_blur"]
     tests = window_gate_tests(f1.pt[inl], uv, 32.0, w, h)
     out = {"workload": "1241x376 stream, 3000 features, search by projection vs 20k map points, one frame "
@@ -449,7 +482,10 @@ def leg_config2(local_rank, check):
            "keypoints": len(f1), "inliers": int(len(inl)), "matched_points": int((got >= 0).sum()),
            "extract_call_ms": round(t_ext * 1e3, 4), "match_call_ms": round(t_match * 1e3, 4),
            "search_by_projection_call_ms": round(t_proj * 1e3, 4),
-           "frames_per_s": round(1.0 / (t_ext + t_match + t_proj), 1),
+           "device_reprojection": {"visible_points": int(nvis.value), "reproject_call_ms": round(t_reproj * 1e3, 4),
+                                   "search_visible_call_ms": round(t_vis * 1e3, 4),
+                                   "matched_points": int((got_v >= 0).sum())},
+           "frames_per_s": round(1.0 / (t_ext + t_match + t_reproj + t_vis), 1),
            "search": {"brute_force_pairs": int(len(inl)) * npts,
                       "window_gate_tests": tests,
                       "gate_tests_per_inlier": round(tests / max(1, len(inl)), 1),
@@ -462,6 +498,8 @@ def leg_config2(local_rank, check):
         want = O.search_by_projection(f1.pt, f1.descriptors, inl, uv, pdesc, ids)
         out["cpu_port_search_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
         assert np.array_equal(got, want), "search by projection differs from the CPU checker"
+        want_v = O.search_by_projection(f1.pt, f1.descriptors, inl, vis_uv, pdesc[vis_idx], vis_idx)
+        assert np.array_equal(got_v, want_v), "search over the device-side visible set differs from the CPU checker"
         out["identical_to_cpu_port"] = True
     return out
 

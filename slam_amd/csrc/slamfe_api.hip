@@ -101,7 +101,14 @@ struct slamfe_ctx {
     int fm_qpt = 1, fm_chunk = 64, fm_nchunks = 1; // plan for frame-vs-frame matching
     Scratch match_part, match_q, match_t, match_o;
     uint8_t* map_desc = nullptr;
-    Scratch pj_in, pj_cand, pj_candn, pj_matched, pj_cells, pj_sorted;
+    Scratch pj_in, pj_cand, pj_candn, pj_matched, pj_cells, pj_sorted, pj_cnt, pj_rank;
+    // The grid over the device-resident visible set (pj_cells, pj_sorted) is built by
+    // slamfe_reproject for the radius of the most recent search (the reference's
+    // constant before any search, Init.cc:242) and reused by the search if the
+    // radius is the same.
+    float pj_grid_radius = 32.0f;
+    bool pj_grid_ready = false;
+    hipEvent_t ev_count = nullptr; // marks the arrival of a count on the host
     Scratch ing_taps, ing_bgr;
     // reprojection: coordinates table (row = Point::id), scratch, and the visible
     // set the last slamfe_reproject call left on the device
@@ -698,12 +705,13 @@ void slamfe_destroy(slamfe_ctx* c)
                     c->band_off, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
                     c->kp_count, c->kps, c->desc, c->kp_mom, c->kp_rot, c->match_out, c->map_desc, c->match_part.p,
                     c->match_q.p, c->match_t.p, c->match_o.p, c->pj_in.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p, c->pj_cells.p,
-                    c->pj_sorted.p, c->ing_taps.p,
+                    c->pj_sorted.p, c->pj_cnt.p, c->pj_rank.p, c->ing_taps.p,
                     c->ing_bgr.p, c->map_xyz, c->rp_uv_all.p, c->rp_mask.p, c->rp_off.p, c->rp_total.p,
                     c->vis_uv.p, c->vis_idx.p, c->tri_in.p, c->tri_out.p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (hipEvent_t e : c->probe_ev) (void)hipEventDestroy(e);
+    if (c->ev_count) (void)hipEventDestroy(c->ev_count);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -1271,6 +1279,19 @@ int slamfe_map_put(slamfe_ctx* c, const int32_t* point_ids, const uint8_t* desc3
 
 namespace {
 
+// Buffers of the grid over R projected points.
+int grow_projection_grid(slamfe_ctx* c, int R)
+{
+    int rc;
+    if ((rc = grow(c, c->pj_cells, slamfe_projection_grid_bytes()))) return rc;
+    if ((rc = grow(c, c->pj_sorted, (size_t)R * 16))) return rc;
+    if (R > SLAMFE_PROJ_ONE_WG_POINTS) {
+        if ((rc = grow(c, c->pj_cnt, slamfe_projection_grid_bytes()))) return rc;
+        if ((rc = grow(c, c->pj_rank, (size_t)R * 4))) return rc;
+    }
+    return SLAMFE_OK;
+}
+
 // The search of Init.cc:229-259 over a visible set that is either uploaded from
 // the host (uv, point_ids) or already on the device (d_uv, d_ids).
 int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n_inl, const float* uv,
@@ -1279,6 +1300,7 @@ int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n
 {
     if (R > SLAMFE_PROJ_MAX_POINTS)
         return fail(c, SLAMFE_E_CAPACITY, "%d visible points; at most %d", R, SLAMFE_PROJ_MAX_POINTS);
+    const bool from_visible_set = d_uv != nullptr;
     HIPCHK(c, hipSetDevice(c->p.device_id));
     int slot = slot_of(c, frame);
     if (slot < 0) return fail(c, SLAMFE_E_HANDLE, "frame handle expired or unknown");
@@ -1311,8 +1333,9 @@ int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n
     if ((rc = grow(c, c->pj_cand, (size_t)n_inl * SLAMFE_PROJ_K * 4))) return rc;
     if ((rc = grow(c, c->pj_candn, (size_t)n_inl * 4))) return rc;
     if ((rc = grow(c, c->pj_matched, (size_t)n_inl * 4))) return rc;
-    if ((rc = grow(c, c->pj_cells, slamfe_projection_grid_bytes()))) return rc;
-    if ((rc = grow(c, c->pj_sorted, (size_t)R * 16))) return rc;
+    // the grid over the visible set: already built by slamfe_reproject for this radius?
+    const bool have_grid = from_visible_set && c->pj_grid_ready && radius == c->pj_grid_radius;
+    if (!have_grid && (rc = grow_projection_grid(c, R))) return rc;
     hipStream_t s = c->stream;
     const size_t o_out = in_bytes;
     if ((rc = pin_reserve(c, o_out + (size_t)n_inl * 4))) return rc;
@@ -1326,11 +1349,20 @@ int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n
     }
     HIPCHK(c, hipMemcpyAsync(c->pj_in.p, c->h_pin, in_bytes, hipMemcpyHostToDevice, s));
     const int32_t* d_idx = (const int32_t*)c->pj_in.p;
+    if (!have_grid) {
+        KCHK(c, slamfe_launch_projection_grid(s, d_uv, d_ids, R, nullptr, radius, c->p.max_width, c->p.max_height,
+                                              (uint32_t*)c->pj_cells.p, c->pj_sorted.p,
+                                              (uint32_t*)c->pj_cnt.p, (uint32_t*)c->pj_rank.p));
+        // a grid over the device-resident visible set stays valid for further searches
+        // with this radius; one over a host-supplied set replaces it
+        c->pj_grid_ready = from_visible_set;
+        c->pj_grid_radius = radius;
+    }
     KCHK(c, slamfe_launch_projection(s, c->kps + (size_t)slot * c->max_kp,
                                      c->desc + (size_t)slot * c->max_kp * 32, nkp,
-                                     d_idx, n_inl, d_uv, d_ids, R, c->map_desc,
+                                     d_idx, n_inl, d_ids, R, c->map_desc,
                                      radius, max_hamming, c->p.max_width, c->p.max_height,
-                                     (uint32_t*)c->pj_cells.p, c->pj_sorted.p, (uint32_t*)c->pj_cand.p,
+                                     (const uint32_t*)c->pj_cells.p, c->pj_sorted.p, (uint32_t*)c->pj_cand.p,
                                      (int32_t*)c->pj_candn.p, (int32_t*)c->pj_matched.p));
     HIPCHK(c, hipMemcpyAsync(c->h_pin + o_out, c->pj_matched.p, (size_t)n_inl * 4,
                              hipMemcpyDeviceToHost, s));
@@ -1417,6 +1449,7 @@ int slamfe_map_put_xyz(slamfe_ctx* c, const int32_t* point_ids, const float* xyz
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->vis_count = -1;
+    c->pj_grid_ready = false;
     return SLAMFE_OK;
 }
 
@@ -1428,6 +1461,7 @@ int slamfe_reproject(slamfe_ctx* c, const float* pose, const float* K, float th,
     if (npoints > c->p.map_capacity)
         return fail(c, SLAMFE_E_CAPACITY, "%d points; map_capacity is %d", npoints, c->p.map_capacity);
     c->vis_count = -1;
+    c->pj_grid_ready = false;
     float kf[16], M[16];
     if (!invert4x4(pose, kf)) return fail(c, SLAMFE_E_INVALID, "the keyframe pose is singular");
     // K4x4 * kf with K4x4 = [K 0; 0 1]; four float products summed left to right
@@ -1451,13 +1485,28 @@ int slamfe_reproject(slamfe_ctx* c, const float* pose, const float* K, float th,
     if ((rc = grow(c, c->vis_uv, (size_t)npoints * 8))) return rc;
     if ((rc = grow(c, c->vis_idx, (size_t)npoints * 4))) return rc;
     hipStream_t s = c->stream;
+    // The grid the search will walk (Init.cc:229-259 follows the reprojection loop
+    // directly) is queued right behind the reprojection kernels, sized for all
+    // npoints and reading the number of visible points where the scan left it, so
+    // that the search call itself is candidates + resolve only.
+    const bool grid_ahead = npoints <= SLAMFE_PROJ_MAX_POINTS && c->pj_grid_radius >= 0.f;
+    if (grid_ahead && (rc = grow_projection_grid(c, npoints))) return rc;
+    if (!c->ev_count) HIPCHK(c, hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming));
     KCHK(c, slamfe_launch_reproject(s, c->map_xyz, npoints, M, th, W, H, (float*)c->rp_uv_all.p,
                                     (uint64_t*)c->rp_mask.p, (int32_t*)c->rp_off.p,
                                     (int32_t*)c->rp_total.p, (float*)c->vis_uv.p, (int32_t*)c->vis_idx.p));
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->rp_total.p, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipEventRecord(c->ev_count, s));
+    if (grid_ahead)
+        KCHK(c, slamfe_launch_projection_grid(s, (const float*)c->vis_uv.p, (const int32_t*)c->vis_idx.p,
+                                              npoints, (const int32_t*)c->rp_total.p, c->pj_grid_radius,
+                                              c->p.max_width, c->p.max_height, (uint32_t*)c->pj_cells.p,
+                                              c->pj_sorted.p, (uint32_t*)c->pj_cnt.p, (uint32_t*)c->pj_rank.p));
+    // the host waits for the count only; the grid is built while it goes on
+    HIPCHK(c, hipEventSynchronize(c->ev_count));
     const int R = c->h_cnt[0];
     c->vis_count = R;
+    c->pj_grid_ready = grid_ahead && R > 0;
     if (n_visible) *n_visible = R;
     if (!uv && !point_idx) return SLAMFE_OK;
     if (R > cap) return fail(c, SLAMFE_E_CAPACITY, "%d visible points exceed the caller's capacity %d", R, cap);

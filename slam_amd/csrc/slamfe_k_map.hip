@@ -4,9 +4,12 @@
 // ---------------------------------------------------------------------------
 // K9  search by projection (Init.cc:229-259).
 //
-// Pass 0 (one workgroup): bucket the visible points into a uniform grid whose
-// cells are at least one search radius wide: count per cell, prefix sum,
-// scatter of {u, v, position, point id} records into cell order.
+// Pass 0: bucket the visible points into a uniform grid whose cells are at
+// least one search radius wide: count per cell, prefix sum, scatter of
+// {u, v, position, point id} records into cell order -- one workgroup for the
+// sets the reference has (up to about 20 000 points), three small launches for
+// larger ones.  The grid depends on the visible set and the radius only, so it
+// can be built as soon as the set exists, ahead of the search call.
 // Pass 1 (parallel, one wavefront per inlier): test the points of the 3 x 3
 // cells around the inlier's keypoint -- pixel distance gate first (Init.cc:389-391
 // arithmetic: float differences, double squares and sqrt, narrowed to float),
@@ -52,66 +55,26 @@ __device__ __forceinline__ int proj_cell_coord(float x, double inv_cell, int n)
     return (int)fmin(fmax(c, 0.0), (double)(n - 1)); // fmax(NaN, 0) = 0
 }
 
-// One workgroup builds the whole grid in LDS: the work is a few loads and LDS
-// atomics per point, far too little for a multi-kernel count / scan / scatter.
-// Its time is the LDS atomics (points cluster, so many lanes hit one counter
-// and are served one after the other) and the memory latency of the one CU
-// that runs it.  So a thread fetches its points in batches of independent
-// loads, and where they fit in registers (R <= 1024 * PROJ_GRID_KEEP) the count
-// pass's atomics return the point's rank inside its cell, which makes the
-// scatter pass atomic-free: position = cell start + rank.
+// One workgroup builds the whole grid in LDS: for the visible sets the
+// reference has, the work is a few loads and LDS atomics per point, too little
+// for a multi-kernel count / scan / scatter.  Its time is the LDS atomics
+// (points cluster, so many lanes hit one counter and are served one after the
+// other) and the memory latency of the one CU that runs it.  So a thread
+// fetches its points in one batch of independent loads and keeps them in
+// registers (R <= 1024 * PROJ_GRID_KEEP), and the count pass's atomics return
+// the point's rank inside its cell, which makes the scatter pass atomic-free:
+// position = cell start + rank.
 #define PROJ_GRID_KEEP 20
-#define PROJ_GRID_BATCH 8
-__global__ __launch_bounds__(1024) void k_proj_grid(const float2* __restrict__ uv,
-                                                     const int32_t* __restrict__ point_ids, int R,
-                                                     slamfe_proj_grid G, uint32_t* __restrict__ cell_start,
-                                                     uint4* __restrict__ sorted)
+#define PROJ_GRID_ONE_WG (1024 * PROJ_GRID_KEEP)
+static_assert(PROJ_GRID_ONE_WG == SLAMFE_PROJ_ONE_WG_POINTS, "one-workgroup limit of the grid build");
+
+// exclusive prefix sum over ncells counters by one workgroup of 1024 threads:
+// cell_start[c] = number of points in cells before c, cell_start[ncells] = total.
+// `starts`, if not null, receives the same values (an LDS copy for the caller).
+__device__ __forceinline__ void proj_scan_cells(const uint32_t* cnt, int ncells, uint32_t* __restrict__ cell_start,
+                                                uint32_t* starts, uint32_t* wtot)
 {
-    extern __shared__ uint32_t glds[]; // ncells counters (later: cell starts / fill cursors), then 16 wave totals
-    const int ncells = G.gx * G.gy;
-    uint32_t* cnt = glds;
-    uint32_t* wtot = glds + ncells;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool keep = R <= 1024 * PROJ_GRID_KEEP; // uniform
-    for (int c = tid; c < ncells; c += 1024) cnt[c] = 0;
-    __syncthreads();
-    float2 kp[PROJ_GRID_KEEP];
-    uint32_t kcr[PROJ_GRID_KEEP]; // cell << 16 | rank inside the cell (both below 2^16 on this path)
-    if (keep) {
-#pragma unroll
-        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
-            const int j = u * 1024 + tid;
-            kp[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
-            const int j = u * 1024 + tid;
-            kcr[u] = 0;
-            if (j < R) {
-                const uint32_t cell = (uint32_t)(proj_cell_coord(kp[u].y, G.inv_cell, G.gy) * G.gx +
-                                                 proj_cell_coord(kp[u].x, G.inv_cell, G.gx));
-                kcr[u] = (cell << 16) | atomicAdd(&cnt[cell], 1u);
-            }
-        }
-    } else {
-        for (int base = 0; base < R; base += 1024 * PROJ_GRID_BATCH) {
-            float2 p[PROJ_GRID_BATCH];
-#pragma unroll
-            for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
-                const int j = base + u * 1024 + tid;
-                p[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
-                const int j = base + u * 1024 + tid;
-                if (j < R)
-                    atomicAdd(&cnt[proj_cell_coord(p[u].y, G.inv_cell, G.gy) * G.gx +
-                                   proj_cell_coord(p[u].x, G.inv_cell, G.gx)], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    // exclusive prefix sum over the cells: every thread owns a run of consecutive cells
     const int per = (ncells + 1023) / 1024;
     const int c0 = min(tid * per, ncells), c1 = min(c0 + per, ncells);
     uint32_t sum = 0;
@@ -128,49 +91,101 @@ __global__ __launch_bounds__(1024) void k_proj_grid(const float2* __restrict__ u
     for (int k = 0; k < wv; ++k) before += wtot[k];
     for (int c = c0; c < c1; ++c) {
         const uint32_t n = cnt[c];
-        cnt[c] = before; // from here on: the cell's start (and fill cursor on the reload path)
+        if (starts) starts[c] = before;
         cell_start[c] = before;
         before += n;
     }
     if (tid == 1023) cell_start[ncells] = before; // == R
+}
+
+__global__ __launch_bounds__(1024) void k_proj_grid(const float2* __restrict__ uv,
+                                                     const int32_t* __restrict__ point_ids, int R,
+                                                     const int32_t* __restrict__ d_R, slamfe_proj_grid G,
+                                                     uint32_t* __restrict__ cell_start,
+                                                     uint4* __restrict__ sorted)
+{
+    extern __shared__ uint32_t glds[]; // ncells counters (later: cell starts), then 16 wave totals
+    if (d_R) R = min(R, *d_R); // the number of points may be known on the device only
+    const int ncells = G.gx * G.gy;
+    uint32_t* cnt = glds;
+    uint32_t* wtot = glds + ncells;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < ncells; c += 1024) cnt[c] = 0;
     __syncthreads();
-    if (keep) {
-        int32_t id[PROJ_GRID_KEEP];
+    float2 kp[PROJ_GRID_KEEP];
+    uint32_t kcr[PROJ_GRID_KEEP]; // cell << 16 | rank inside the cell (both below 2^16 here)
 #pragma unroll
-        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
-            const int j = u * 1024 + tid;
-            id[u] = j < R ? point_ids[j] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
-            const int j = u * 1024 + tid;
-            if (j < R)
-                sorted[cnt[kcr[u] >> 16] + (kcr[u] & 0xffffu)] =
-                    make_uint4(__float_as_uint(kp[u].x), __float_as_uint(kp[u].y), (uint32_t)j, (uint32_t)id[u]);
-        }
-        return;
+    for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+        const int j = u * 1024 + tid;
+        kp[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
     }
-    for (int base = 0; base < R; base += 1024 * PROJ_GRID_BATCH) {
-        float2 p[PROJ_GRID_BATCH];
-        int32_t id[PROJ_GRID_BATCH];
 #pragma unroll
-        for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
-            const int j = base + u * 1024 + tid;
-            p[u] = j < R ? uv[j] : make_float2(0.f, 0.f);
-            id[u] = j < R ? point_ids[j] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < PROJ_GRID_BATCH; ++u) {
-            const int j = base + u * 1024 + tid;
-            if (j < R) {
-                const int cell = proj_cell_coord(p[u].y, G.inv_cell, G.gy) * G.gx +
-                                 proj_cell_coord(p[u].x, G.inv_cell, G.gx);
-                const uint32_t pos = atomicAdd(&cnt[cell], 1u);
-                sorted[pos] = make_uint4(__float_as_uint(p[u].x), __float_as_uint(p[u].y), (uint32_t)j,
-                                         (uint32_t)id[u]);
-            }
+    for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+        const int j = u * 1024 + tid;
+        kcr[u] = 0;
+        if (j < R) {
+            const uint32_t cell = (uint32_t)(proj_cell_coord(kp[u].y, G.inv_cell, G.gy) * G.gx +
+                                             proj_cell_coord(kp[u].x, G.inv_cell, G.gx));
+            kcr[u] = (cell << 16) | atomicAdd(&cnt[cell], 1u);
         }
     }
+    __syncthreads();
+    proj_scan_cells(cnt, ncells, cell_start, cnt, wtot); // cnt: from here on the cells' starts
+    __syncthreads();
+    int32_t id[PROJ_GRID_KEEP];
+#pragma unroll
+    for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+        const int j = u * 1024 + tid;
+        id[u] = j < R ? point_ids[j] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PROJ_GRID_KEEP; ++u) {
+        const int j = u * 1024 + tid;
+        if (j < R)
+            sorted[cnt[kcr[u] >> 16] + (kcr[u] & 0xffffu)] =
+                make_uint4(__float_as_uint(kp[u].x), __float_as_uint(kp[u].y), (uint32_t)j, (uint32_t)id[u]);
+    }
+}
+
+// Larger visible sets: the same three steps as launches of their own, so that the
+// whole chip counts and scatters.  Count: one lane per point, the atomic on the
+// cell's counter (in memory, zeroed by the caller) returns the point's rank in its
+// cell.  Scan: one workgroup.  Scatter: position = cell start + rank, no atomics.
+__global__ __launch_bounds__(256) void k_proj_grid_count(const float2* __restrict__ uv, int R,
+                                                          const int32_t* __restrict__ d_R,
+                                                          slamfe_proj_grid G, uint32_t* __restrict__ cell_cnt,
+                                                          uint32_t* __restrict__ rank)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (d_R) R = min(R, *d_R);
+    if (j >= R) return;
+    const float2 p = uv[j];
+    const int cell = proj_cell_coord(p.y, G.inv_cell, G.gy) * G.gx + proj_cell_coord(p.x, G.inv_cell, G.gx);
+    rank[j] = atomicAdd(&cell_cnt[cell], 1u);
+}
+
+__global__ __launch_bounds__(1024) void k_proj_grid_scan(const uint32_t* __restrict__ cell_cnt, int ncells,
+                                                          uint32_t* __restrict__ cell_start)
+{
+    __shared__ uint32_t wtot[16];
+    proj_scan_cells(cell_cnt, ncells, cell_start, nullptr, wtot);
+}
+
+__global__ __launch_bounds__(256) void k_proj_grid_scatter(const float2* __restrict__ uv,
+                                                            const int32_t* __restrict__ point_ids, int R,
+                                                            const int32_t* __restrict__ d_R,
+                                                            slamfe_proj_grid G,
+                                                            const uint32_t* __restrict__ cell_start,
+                                                            const uint32_t* __restrict__ rank,
+                                                            uint4* __restrict__ sorted)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (d_R) R = min(R, *d_R);
+    if (j >= R) return;
+    const float2 p = uv[j];
+    const int cell = proj_cell_coord(p.y, G.inv_cell, G.gy) * G.gx + proj_cell_coord(p.x, G.inv_cell, G.gx);
+    sorted[cell_start[cell] + rank[j]] =
+        make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), (uint32_t)j, (uint32_t)point_ids[j]);
 }
 
 // Bitonic sort of 64 keys held one per lane, ascending by lane.
@@ -554,21 +569,52 @@ static slamfe_proj_grid proj_grid_for(float radius, int max_w, int max_h)
 
 size_t slamfe_projection_grid_bytes(void) { return ((size_t)PROJ_GRID_MAX * PROJ_GRID_MAX + 1) * sizeof(uint32_t); }
 
+// Pass 0 of the search: the grid over the projected points (uv, point_ids in device
+// memory) for a search radius.  There are R points, or min(R, *d_R) if d_R is not
+// null (a count that is known on the device only: the grid can then be queued
+// behind the kernels that make the points, without a host round trip).  cell_cnt
+// (as many bytes as cell_start) and rank (R words) are used only where R exceeds
+// what the one-workgroup kernel holds.
+int slamfe_launch_projection_grid(hipStream_t s, const float* uv, const int32_t* point_ids, int R,
+                                  const int32_t* d_R, float radius, int max_w, int max_h,
+                                  uint32_t* cell_start, void* sorted, uint32_t* cell_cnt, uint32_t* rank)
+{
+    if (R <= 0) return 0;
+    const slamfe_proj_grid G = proj_grid_for(radius, max_w, max_h);
+    const int ncells = G.gx * G.gy;
+    if (R <= PROJ_GRID_ONE_WG) {
+        hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(1024), ((size_t)ncells + 16) * sizeof(uint32_t), s,
+                           reinterpret_cast<const float2*>(uv), point_ids, R, d_R, G, cell_start,
+                           reinterpret_cast<uint4*>(sorted));
+        LAUNCH_CHECK();
+        return 0;
+    }
+    hipError_t e = hipMemsetAsync(cell_cnt, 0, (size_t)ncells * sizeof(uint32_t), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_proj_grid_count, dim3((R + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(uv), R, d_R, G, cell_cnt, rank);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_proj_grid_scan, dim3(1), dim3(1024), 0, s, cell_cnt, ncells, cell_start);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_proj_grid_scatter, dim3((R + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(uv), point_ids, R, d_R, G, cell_start, rank,
+                       reinterpret_cast<uint4*>(sorted));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// Passes 1 and 2 over a grid built by slamfe_launch_projection_grid for the same
+// radius and frame-size limits.
 int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
-                             const int32_t* kp_idx, int n_inl, const float* uv,
-                             const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
-                             int max_hamming, int max_w, int max_h, uint32_t* cell_start, void* sorted,
-                             uint32_t* cand, int32_t* cand_n, int32_t* matched)
+                             const int32_t* kp_idx, int n_inl, const int32_t* point_ids, int R,
+                             const uint8_t* map_desc, float radius, int max_hamming, int max_w, int max_h,
+                             const uint32_t* cell_start, const void* sorted, uint32_t* cand, int32_t* cand_n,
+                             int32_t* matched)
 {
     if (n_inl <= 0) return 0;
     const double gate_dd = slamfe_proj_gate_threshold(radius);
     if (max_hamming > 256) max_hamming = 256; // no two rows are further apart
     const slamfe_proj_grid G = proj_grid_for(radius, max_w, max_h);
-    const int ncells = G.gx * G.gy;
-    hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(1024), ((size_t)ncells + 16) * sizeof(uint32_t), s,
-                       reinterpret_cast<const float2*>(uv), point_ids, R, G, cell_start,
-                       reinterpret_cast<uint4*>(sorted));
-    LAUNCH_CHECK();
     hipLaunchKernelGGL(k_proj_candidates, dim3((n_inl + 3) / 4), dim3(256), 0, s, kps,
                        reinterpret_cast<const uint32_t*>(fdesc), nkp, kp_idx, n_inl, G, cell_start,
                        reinterpret_cast<const uint4*>(sorted), reinterpret_cast<const uint32_t*>(map_desc),

@@ -83,11 +83,19 @@ int slamfe_launch_merge_shard_keys(hipStream_t s, const uint64_t* d_keys, int ns
 
 #define SLAMFE_PROJ_K 32
 #define SLAMFE_PROJ_MAX_POINTS (1 << 19)
+// the grid over the projected points (pass 0 of the search); cell_cnt and rank are
+// needed only above SLAMFE_PROJ_ONE_WG_POINTS points
+#define SLAMFE_PROJ_ONE_WG_POINTS 20480
+int slamfe_launch_projection_grid(hipStream_t s, const float* uv, const int32_t* point_ids, int R,
+                                  const int32_t* d_R /* or null: min(R, *d_R) points */,
+                                  float radius, int max_w, int max_h, uint32_t* cell_start /* grid_bytes */,
+                                  void* sorted /* R * 16 bytes */, uint32_t* cell_cnt /* grid_bytes */,
+                                  uint32_t* rank /* R * 4 bytes */);
+// candidates + resolve over that grid (same radius, max_w, max_h)
 int slamfe_launch_projection(hipStream_t s, const slamfe_keypoint* kps, const uint8_t* fdesc, int nkp,
-                             const int32_t* kp_idx, int n_inl, const float* uv,
-                             const int32_t* point_ids, int R, const uint8_t* map_desc, float radius,
-                             int max_hamming, int max_w, int max_h, uint32_t* cell_start /* grid_bytes */,
-                             void* sorted /* R * 16 bytes */, uint32_t* cand, int32_t* cand_n,
+                             const int32_t* kp_idx, int n_inl, const int32_t* point_ids, int R,
+                             const uint8_t* map_desc, float radius, int max_hamming, int max_w, int max_h,
+                             const uint32_t* cell_start, const void* sorted, uint32_t* cand, int32_t* cand_n,
                              int32_t* matched);
 size_t slamfe_projection_grid_bytes(void);
 int slamfe_launch_reproject(hipStream_t s, const float* xyz, int npoints, const float* M16, float th,

@@ -213,6 +213,21 @@ def camera_scene(npoints: int, w: int, h: int, seed: int = 7):
     return pose, K, world.astype(np.float32), th
 
 
+def scene_from_uv(uv: np.ndarray, w: int, h: int, seed: int = 15):
+    """Map points that the reprojection of Init.cc:203-218 puts at the given pixel
+    positions (to within float rounding): identity keyframe pose, the intrinsics of
+    Init.cc:90-99, depths between 1 and 19 (inside the depth gate around th = 0).
+    Returns (pose 4x4 f32, K 3x3 f32, xyz [n,3] f32, th)."""
+    uv = np.asarray(uv, np.float64).reshape(-1, 2)
+    idx = np.arange(len(uv), dtype=np.uint64)
+    z = 1.0 + 18.0 * (hash_u64(seed, 1, idx) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    K = np.eye(3, dtype=np.float32)
+    K[0, 0] = K[1, 1] = 984.0
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    xyz = np.stack([(uv[:, 0] - w / 2.0) / 984.0 * z, (uv[:, 1] - h / 2.0) / 984.0 * z, z], 1)
+    return np.eye(4, dtype=np.float32), K, xyz.astype(np.float32), 0.0
+
+
 def two_view_scene(npoints: int, w: int, h: int, seed: int = 9):
     """Two camera projection matrices as Init.cc:168-195 builds them (P1 = K[I|0],
     P2 = K[R|t], f = 984) and the pixel positions of npoints scene points in both

@@ -658,6 +658,69 @@ def test_reproject_then_search_on_device(fe_orb):
     assert np.array_equal(fe_orb.search_by_projection(f, kp_idx, want_uv, want_idx), want)
 
 
+@pytest.mark.parametrize("n", [6000, 90_000])
+def test_visible_set_grid_is_reused_and_rebuilt(n):
+    # The grid over the visible set is built by the reprojection call (for the radius of
+    # the most recent search) and reused by the searches that follow; a search with
+    # another radius, a host-supplied visible set in between, new coordinates or a new
+    # pose must each lead to a grid that fits.  90 000 points: the visible set is beyond
+    # what the one-workgroup grid kernel holds (count / scan / scatter launches).
+    from slam_amd.frontend import FrontEnd
+    w, h = 640, 480
+    with FrontEnd(mode=abi.MODE_ORB, fast_threshold=20, nfeatures=2000, max_width=w, max_height=h,
+                  max_batch=1, map_capacity=n) as fe:
+        f = fe.extract_keypoints(synth.textured_canvas(w, h, 72))
+        xy = np.stack([f.keypoints["x"], f.keypoints["y"]], 1)
+        pose, K, xyz, th = synth.camera_scene(n, w, h, 14)
+        rng = np.random.default_rng(8)
+        desc = synth.random_descriptors(n, 17, 1)
+        near = rng.integers(0, len(f), n)
+        take = rng.random(n) < 0.6  # these look like some keypoint of the frame, a few bits off
+        desc[take] = f.descriptors[near[take]]
+        desc[take, rng.integers(0, 32, take.sum())] ^= np.uint8(4)
+        fe.map_put(np.arange(n), desc)
+        fe.map_put_xyz(np.arange(n), xyz)
+        kp_idx = rng.permutation(len(f))[:700].astype(np.int32)
+
+        def check(pose_, xyz_, radius, label):
+            uv, idx = O.reproject(pose_, K, xyz_, th, w, h)
+            want = O.search_by_projection(xy, f.descriptors, kp_idx, uv, desc[idx], idx, radius=radius)
+            got = fe.search_by_projection_visible(f, kp_idx, radius=radius)
+            assert np.array_equal(got, want), label
+            return uv, idx, want
+
+        assert fe.reproject(pose, K, th, w, h, n, download=False) > (1000 if n < 10_000 else SLAMFE_ONE_WG)
+        uv, idx, want32 = check(pose, xyz, 32.0, "grid from the reprojection call")
+        assert (want32 >= 0).sum() > 50
+        check(pose, xyz, 32.0, "same grid again")
+        check(pose, xyz, 9.5, "other radius: rebuilt")
+        check(pose, xyz, 9.5, "and kept")
+        # a host-supplied visible set uses the same buffers
+        sub = slice(0, len(idx) // 2)
+        got = fe.search_by_projection(f, kp_idx, uv[sub], idx[sub], radius=20.0)
+        assert np.array_equal(got, O.search_by_projection(xy, f.descriptors, kp_idx, uv[sub], desc[idx[sub]],
+                                                           idx[sub], radius=20.0))
+        check(pose, xyz, 20.0, "visible set after a host-supplied one")
+        # new pose: the next reprojection builds the grid for the last radius (20)
+        pose2 = pose.copy()
+        pose2[0, 3] += 0.3
+        fe.reproject(pose2, K, th, w, h, n, download=False)
+        check(pose2, xyz, 20.0, "new pose, last radius")
+        check(pose2, xyz, 32.0, "new pose, other radius")
+        # new coordinates drop the visible set altogether
+        xyz2 = xyz.copy()
+        xyz2[: n // 3, 0] += 0.2
+        fe.map_put_xyz(np.arange(n), xyz2)
+        from slam_amd.frontend import SlamfeError
+        with pytest.raises(SlamfeError):
+            fe.search_by_projection_visible(f, kp_idx)
+        fe.reproject(pose2, K, th, w, h, n, download=False)
+        check(pose2, xyz2, 32.0, "after new coordinates")
+
+
+SLAMFE_ONE_WG = 20480  # points the one-workgroup grid kernel takes
+
+
 @pytest.mark.parametrize("radius", [32.0, 31.7, 0.0, 1.0, 5.000001, 1e9, -1.0])
 def test_search_by_projection_radius_boundary(fe_orb, radius):
     # points placed on and next to the circle of the given radius around their

@@ -45,8 +45,26 @@ def case(npts, ninl_cap, reps):
             ts.append(time.perf_counter() - t0)
         t = float(np.median(ts))
         tests = window_tests(f1.pt[inl], uv, 32.0, w, h)
+        # the same search over the visible set the device-side reprojection leaves
+        pose, K, xyz, th = synth.scene_from_uv(uv, w, h)
+        fe.map_put_xyz(ids, xyz)
+        tr, tv = [], []
+        for it in range(reps + 3):
+            t0 = time.perf_counter()
+            nvis = fe.reproject(pose, K, th, w, h, npts, download=False)
+            t1 = time.perf_counter()
+            rc = fe._lib.slamfe_search_by_projection_visible(fe._ctx, C.c_uint64(f1.handle), inl.ctypes.data,
+                                                             len(inl), C.c_float(32.0), 128, matched.ctypes.data)
+            t2 = time.perf_counter()
+            assert rc == 0, rc
+            if it >= 3:
+                tr.append(t1 - t0)
+                tv.append(t2 - t1)
         return {"visible_points": npts, "inliers": int(len(inl)), "matched": int((matched >= 0).sum()),
-                "call_ms": round(t * 1e3, 4), "brute_force_pairs": int(len(inl)) * npts,
+                "call_ms": round(t * 1e3, 4),
+                "visible_form": {"visible_points": int(nvis), "reproject_call_ms": round(float(np.median(tr)) * 1e3, 4),
+                                 "search_call_ms": round(float(np.median(tv)) * 1e3, 4)},
+                "brute_force_pairs": int(len(inl)) * npts,
                 "window_gate_tests": tests, "gate_tests_per_s": round(tests / t, 1),
                 "brute_force_pairs_per_s_equivalent": round(len(inl) * npts / t, 1)}
 
