@@ -611,6 +611,9 @@ def main():
                     help="skip everything that runs the CPU checker (baseline leg and output checks)")
     ap.add_argument("--no-reloc", action="store_true", help="skip the 1M-row matching leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the host-path and other-config legs")
+    ap.add_argument("--reloc-sets-per-collective", type=int, default=1,
+                    help="query sets of 2000 matched per all-gather in the sharded relocalisation leg "
+                         "(1, 4 and 16 are always reported; this adds another value)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group, barriers, all-gather) even "
                          "with one rank: a rehearsal of the N > 1 run on a one-GPU box")
@@ -783,73 +786,127 @@ def main():
         try:
             NQ, NT = 2000, 1_000_000
             lo, hi = sharding.shard_bounds(NT, world, rank)
-            q_np = synth.random_descriptors(NQ, 3, 5)
             shard = torch.from_numpy(synth.random_descriptors(hi - lo, 3 + 101 * rank, 6)).to(dev)
-            dq = torch.from_numpy(q_np).to(dev)
-            keys = torch.empty((NQ, 2), dtype=torch.int64, device=dev)
-            gathered = torch.empty((world, NQ, 2), dtype=torch.int64, device=dev)
-            out = torch.empty((NQ, 16), dtype=torch.uint8, device=dev)
+            R = 50
 
-            def reloc():
-                fe.match_shard_keys(dq.data_ptr(), NQ, shard.data_ptr(), hi - lo, lo, keys.data_ptr())
-                if multi:
-                    dist.all_gather_into_tensor(gathered, keys)
-                    fe.merge_shard_keys(gathered.data_ptr(), world, NQ, out.data_ptr())
-                else:
-                    fe.merge_shard_keys(keys.data_ptr(), 1, NQ, out.data_ptr())
+            def reloc_job(K):
+                """K query sets per collective: one match launch for K x 2000 queries, one
+                all-gather of K x 32 KB per rank, one merge launch.  Returns the functions
+                of the three phases and the whole sequence."""
+                dq = torch.from_numpy(synth.random_descriptors(K * NQ, 3, 5)).to(dev)
+                keys = torch.empty((K * NQ, 2), dtype=torch.int64, device=dev)
+                gathered = torch.empty((world, K * NQ, 2), dtype=torch.int64, device=dev)
+                out = torch.empty((K * NQ, 16), dtype=torch.uint8, device=dev)
 
-            with torch.cuda.stream(stream):
-                for _ in range(50):  # (the chip takes some tens of launches to reach its clock)
-                    reloc()
-                torch.cuda.synchronize(dev)
-                if multi:
-                    host_barrier()
-                torch.cuda.synchronize(dev)
-                r0 = time.perf_counter()
-                R = 50
-                for _ in range(R):
-                    reloc()
-                torch.cuda.synchronize(dev)
-                if multi:
-                    host_barrier()
-                rel = time.perf_counter() - r0
-            if multi:
-                t = torch.tensor([rel], dtype=torch.float64, device=dev)
+                def match(k=keys):
+                    fe.match_shard_keys(dq.data_ptr(), K * NQ, shard.data_ptr(), hi - lo, lo, k.data_ptr())
+
+                def gather():
+                    if multi:
+                        dist.all_gather_into_tensor(gathered, keys)
+
+                def merge(g=None):
+                    if multi:
+                        fe.merge_shard_keys((gathered if g is None else g).data_ptr(), world, K * NQ, out.data_ptr())
+                    else:
+                        fe.merge_shard_keys(keys.data_ptr(), 1, K * NQ, out.data_ptr())
+
+                def whole():
+                    match()
+                    gather()
+                    merge()
+                return {"match": match, "gather": gather, "merge": merge, "whole": whole, "keys": keys,
+                        "gathered": gathered}
+
+            def max_over_ranks(x):
+                if not multi:
+                    return x
+                t = torch.tensor([x], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                rel = float(t.item())
-            hamming["reloc_2000x1M_gcmps"] = round(NQ * NT * R / rel / 1e9, 2)
-            if multi:
-                # throughput with successive query sets pipelined: the all-gather of
-                # set i (on RCCL's stream) overlaps the match kernel of set i+1
-                keys2 = [keys, torch.empty_like(keys)]
-                gath2 = [gathered, torch.empty_like(gathered)]
+                return float(t.item())
 
-                def pipelined(count):
-                    works = [None, None]
-                    for it in range(count + 2):
-                        b = it & 1
-                        if works[b] is not None:
-                            works[b].wait()
-                            fe.merge_shard_keys(gath2[b].data_ptr(), world, NQ, out.data_ptr())
-                            works[b] = None
-                        if it < count:
-                            fe.match_shard_keys(dq.data_ptr(), NQ, shard.data_ptr(), hi - lo, lo,
-                                                keys2[b].data_ptr())
-                            works[b] = dist.all_gather_into_tensor(gath2[b], keys2[b], async_op=True)
-
+            def time_reloc(K):
+                job = reloc_job(K)
+                res = {}
                 with torch.cuda.stream(stream):
-                    pipelined(4)
+                    for _ in range(50 if K == 1 else 10):  # (the chip takes some tens of launches to reach its clock)
+                        job["whole"]()
                     torch.cuda.synchronize(dev)
-                    host_barrier()
+                    if multi:
+                        host_barrier()
                     torch.cuda.synchronize(dev)
-                    p0 = time.perf_counter()
-                    pipelined(R)
+                    r0 = time.perf_counter()
+                    for _ in range(R):
+                        job["whole"]()
                     torch.cuda.synchronize(dev)
-                    host_barrier()
-                    pl = time.perf_counter() - p0
-                t = torch.tensor([pl], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                hamming["reloc_pipelined_gcmps"] = round(NQ * NT * R / float(t.item()) / 1e9, 2)
+                    if multi:
+                        host_barrier()
+                    rel = max_over_ranks(time.perf_counter() - r0)
+                    res["gcmps"] = round(K * NQ * NT * R / rel / 1e9, 2)
+                    res["ms_per_query_set"] = round(rel / R / K * 1e3, 4)
+                    # the three phases between HIP events on the stream they are queued on
+                    # (a synchronous collective makes this stream wait for its end)
+                    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(R)]
+                    for e in ev:
+                        e[0].record()
+                        job["match"]()
+                        e[1].record()
+                        job["gather"]()
+                        e[2].record()
+                        job["merge"]()
+                        e[3].record()
+                    torch.cuda.synchronize(dev)
+                    ph = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i in range(3)]
+                    res["phases_ms"] = {"match_kernel": round(max_over_ranks(ph[0]), 4),
+                                        "all_gather": round(max_over_ranks(ph[1]), 4) if multi else None,
+                                        "merge": round(max_over_ranks(ph[2]), 4)}
+                    if multi:
+                        # successive collectives pipelined: the all-gather of step i (on RCCL's
+                        # stream) overlaps the match kernel of step i+1
+                        keys2 = [job["keys"], torch.empty_like(job["keys"])]
+                        gath2 = [job["gathered"], torch.empty_like(job["gathered"])]
+
+                        def pipelined(count):
+                            works = [None, None]
+                            for it in range(count + 2):
+                                b = it & 1
+                                if works[b] is not None:
+                                    works[b].wait()
+                                    job["merge"](gath2[b])
+                                    works[b] = None
+                                if it < count:
+                                    job["match"](keys2[b])
+                                    works[b] = dist.all_gather_into_tensor(gath2[b], keys2[b], async_op=True)
+
+                        pipelined(4)
+                        torch.cuda.synchronize(dev)
+                        host_barrier()
+                        torch.cuda.synchronize(dev)
+                        p0 = time.perf_counter()
+                        pipelined(R)
+                        torch.cuda.synchronize(dev)
+                        host_barrier()
+                        pl = max_over_ranks(time.perf_counter() - p0)
+                        res["pipelined_gcmps"] = round(K * NQ * NT * R / pl / 1e9, 2)
+                return res, rel
+
+            ks = sorted({1, 4, 16, max(1, args.reloc_sets_per_collective)})
+            per_k = {}
+            rel = None
+            for K in ks:
+                per_k[str(K)], rel_k = time_reloc(K)
+                if K == 1:
+                    rel = rel_k
+            hamming["reloc_2000x1M_gcmps"] = per_k["1"]["gcmps"]
+            hamming["reloc_phases_ms"] = per_k["1"]["phases_ms"]
+            if multi:
+                hamming["reloc_pipelined_gcmps"] = {k: v["pipelined_gcmps"] for k, v in per_k.items()}
+            # K query sets per collective: at 8 ranks a rank's share of one set is some tens of
+            # microseconds of kernel against one latency-bound all-gather; K sets share one
+            hamming["reloc_sets_per_collective"] = per_k
+            hamming["reloc_sets_per_collective_selected"] = max(1, args.reloc_sets_per_collective)
+            dq = torch.from_numpy(synth.random_descriptors(NQ, 3, 5)).to(dev)
+            keys = torch.empty((NQ, 2), dtype=torch.int64, device=dev)
             if world == 1 and not multi:
                 # the same job on the vector-ALU popcount kernel (v_xor + v_bcnt), against
                 # the measured integer-VALU ceiling: 16 lane-ops per comparison

@@ -491,6 +491,40 @@ def test_match_sharded_keys_merge_equals_single(fe_orb):
         assert np.array_equal(got[name], want[name]), name
 
 
+def test_stacked_query_sets_share_one_match_and_one_merge(fe_orb):
+    # K query sets per collective in the sharded relocalisation: one match call over the
+    # K stacked sets per shard, one merge call over [shard][K * nq][2] keys -- the rows
+    # must be those of K separate match + merge sequences, and of the CPU checker
+    import torch
+    K, nq, nt, shards = 5, 211, 9000, 3
+    q, t = synth.descriptor_sets(K * nq, nt, seed=19, dup_percent=2)
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    bounds = [0, 4097, 4100, nt]
+    stacked = torch.empty((shards, K * nq, 2), dtype=torch.int64, device="cuda")
+    out_stacked = torch.zeros(K * nq * 16, dtype=torch.uint8, device="cuda")
+    single = torch.empty((shards, nq, 2), dtype=torch.int64, device="cuda")
+    out_single = torch.zeros(nq * 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for s in range(shards):
+        lo, hi = bounds[s], bounds[s + 1]
+        fe_orb.match_shard_keys(dq.data_ptr(), K * nq, dt[lo:hi].data_ptr(), hi - lo, lo, stacked[s].data_ptr())
+    fe_orb.merge_shard_keys(stacked.data_ptr(), shards, K * nq, out_stacked.data_ptr())
+    fe_orb.sync()
+    got = out_stacked.cpu().numpy().view(abi.MATCH2_DTYPE)
+    want = O.match_knn2(q, t)
+    for k in range(K):
+        for s in range(shards):
+            lo, hi = bounds[s], bounds[s + 1]
+            fe_orb.match_shard_keys(dq[k * nq:(k + 1) * nq].data_ptr(), nq, dt[lo:hi].data_ptr(), hi - lo, lo,
+                                    single[s].data_ptr())
+        fe_orb.merge_shard_keys(single.data_ptr(), shards, nq, out_single.data_ptr())
+        fe_orb.sync()
+        one = out_single.cpu().numpy().view(abi.MATCH2_DTYPE)
+        for name in ("idx0", "idx1", "d0", "d1", "ratio_pass", "nfound"):
+            assert np.array_equal(got[name][k * nq:(k + 1) * nq], one[name]), (k, name)
+            assert np.array_equal(one[name], want[name][k * nq:(k + 1) * nq]), (k, name)
+
+
 # ------------------------------------------------------ search by projection
 def test_search_by_projection(fe_orb):
     img = synth.textured_canvas(1241, 376, 50)
