@@ -43,6 +43,10 @@ def main():
     write = row_of(os.path.join(src, "pmc_write_size_summary.csv"), "k_fast_blur")
     sq = row_of(os.path.join(src, "pmc_sq_summary.csv"), "k_fast_blur")
     frames = 256
+    try:  # frames per launch of the profiled bench runs (its default batch)
+        frames = int(json.load(open(os.path.join(src, "bench.json")))["config"]["frames_per_step"])
+    except Exception:
+        pass
     lv = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
     alg = sum(w * h for w, h in lv) * frames
     fetch_kb, write_kb = float(fetch["FETCH_SIZE"]), float(write["WRITE_SIZE"])
@@ -53,8 +57,8 @@ def main():
     out = {
         "_note": "HBM-side bytes and instruction counts per k_fast_blur launch from rocprofv3 --pmc (separate "
                  "passes for FETCH_SIZE, WRITE_SIZE and the SQ counters; tools/collect_profiles.sh: bench.py "
-                 "--no-cpu --no-reloc --no-legs --steps 3 --warmup 1 --streams 1, 256 frames of 640x480 per "
-                 "launch). Counter unit KB. FETCH_SIZE is doubled: on gfx950 it tallies 128-B requests at 64 B "
+                 "--no-cpu --no-reloc --no-legs --steps 3 --warmup 1 --streams 1, frames_per_launch frames of "
+                 "640x480 per launch). Counter unit KB. FETCH_SIZE is doubled: on gfx950 it tallies 128-B requests at 64 B "
                  "(calibrated on a plain copy kernel: reads 78,643,200 B, FETCH_SIZE 38,411.8 KB = 0.500x; "
                  "WRITE_SIZE read exactly).",
         "measured_on": {"commit": head + ("+uncommitted kernel changes" if dirty else ""),
@@ -66,7 +70,7 @@ def main():
         "frames_per_launch": frames,
         "fast_blur_wave_insts": int(float(sq["SQ_INSTS_VALU"])),
         "fast_blur_mfma_insts": int(float(sq["SQ_INSTS_MFMA"])),
-        "_note_wave_insts": "SQ_INSTS_VALU / SQ_INSTS_MFMA per k_fast_blur launch of 256 frames",
+        "_note_wave_insts": "SQ_INSTS_VALU / SQ_INSTS_MFMA per k_fast_blur launch of frames_per_launch frames",
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
