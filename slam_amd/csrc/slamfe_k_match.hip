@@ -349,6 +349,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // table lookup (4 LDS reads per dword instead of two dozen vector operations)
     __shared__ uint32_t lut[256];
     lut[tid] = bits8_to_nibbles((uint32_t)tid) * 6u;
+    // ... and byte -> eight nibbles of 6 (+4.0, bit clear) / 0xe (-4.0, bit set) for
+    // the query rows: 32 table reads per lane instead of a few hundred vector
+    // operations at the start of every workgroup
+    __shared__ uint32_t qlut[256];
+    qlut[tid] = 0x66666666u | (bits8_to_nibbles((uint32_t)tid) << 3);
+    __syncthreads();
 
     // query fragments: the instruction's 64 bit positions are two dwords of the
     // row, one per lane half; lane (r, h) holds dword 2 kb + h of its query row
@@ -369,8 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int kb = 0; kb < 4; ++kb) {
             const uint32_t mine = h ? qw[2 * kb + 1] : qw[2 * kb];
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                B[blk][kb][n] = (int)(0x66666666u | (bits8_to_nibbles((mine >> (8 * n)) & 0xffu) << 3));
+            for (int n = 0; n < 4; ++n) B[blk][kb][n] = (int)qlut[(mine >> (8 * n)) & 0xffu];
         }
         pq[blk] = pc;
     }
@@ -392,7 +397,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     const int ntiles = (j1 - j0 + MM_TILE - 1) / MM_TILE;
     const int nstages = (ntiles + MM_SUB - 1) / MM_SUB;
-    __syncthreads(); // the lookup table is complete
     // Three stage buffers: the rows of stage s+1 are fetched from memory during
     // stage s-1 and written to LDS in the middle of stage s, so that a wave reaches
     // the barrier at the end of a stage with nothing of its own pending.

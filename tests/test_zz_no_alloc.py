@@ -50,10 +50,16 @@ def test_static_scratch_keys_equal_growable_buffer_keys(kernel):
             assert np.array_equal(_keys(fe2, fe2.match_shard_keys_static, dq, nq, dt, nt, base),
                                   _keys(fe, fe.match_shard_keys, dq, nq, dt, nt, base))
         # 2000 x 1M, the relocalisation job, fits; a job whose partials exceed 4 MiB is
-        # refused before anything is launched (the pointers are never touched)
+        # refused before anything is launched.  (Every pointer handed over is valid for the
+        # sizes named all the same: a test must not depend on a refusal to stay in bounds.)
+        nq_big = 300_000 if kernel == abi.MATCH_POPCOUNT else 600_000
+        big_q = torch.zeros((nq_big, 32), dtype=torch.uint8, device="cuda")
+        big_keys = torch.zeros((nq_big, 2), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
         with pytest.raises(SlamfeError) as e:
-            fe.match_shard_keys_static(dq.data_ptr(), 20000, dt.data_ptr(), 1_000_000, 0, dq.data_ptr())
+            fe.match_shard_keys_static(big_q.data_ptr(), nq_big, dt.data_ptr(), nt_max, 0, big_keys.data_ptr())
         assert e.value.code == abi.SLAMFE_E_CAPACITY and "static scratch" in str(e.value)
+        del big_q, big_keys
         # empty query set: nothing to do
         fe.match_shard_keys_static(0, 0, dt.data_ptr(), 10, 0, dq.data_ptr())
 
@@ -61,28 +67,38 @@ def test_static_scratch_keys_equal_growable_buffer_keys(kernel):
 def test_static_entry_point_allocates_no_device_memory():
     """The property the entry point exists for: device memory in use does not change over
     its calls, on a context whose growable partial-result buffer has never been sized (a
-    call routed through that buffer would have to allocate here).  The job is the
-    relocalisation one, 2000 x 1,000,000, whose partials (3.9 MiB) nearly fill the array;
-    its keys are compared with the growable entry point's afterwards."""
+    call routed through that buffer would have to allocate here).  The jobs: the
+    relocalisation one, 2000 x 1,000,000, whose partials (3.9 MiB) nearly fill the 4 MiB
+    array; a smaller one after it; and 170,000 queries x 10,000 rows (3 chunks: 3.9 MiB).
+    The keys are compared with the growable entry point's afterwards."""
     import torch
     from slam_amd.frontend import FrontEnd
     nq, nt = 2000, 1_000_000
+    nq_wide, nt_wide = 170_000, 10_000
     q, t = synth.descriptor_sets(nq, nt, seed=53, dup_percent=1)
     dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    wide_q = torch.from_numpy(synth.random_descriptors(nq_wide, 57, 2)).cuda()
     keys = torch.full((nq, 2), -7, dtype=torch.int64, device="cuda")
     keys_small = torch.full((nq, 2), -7, dtype=torch.int64, device="cuda")
+    keys_wide = torch.full((nq_wide, 2), -7, dtype=torch.int64, device="cuda")
+    keys_wide_want = torch.full((nq_wide, 2), -7, dtype=torch.int64, device="cuda")
     with FrontEnd(mode=abi.MODE_ORB, max_width=64, max_height=64, max_batch=1, map_capacity=0,
                   max_keypoints=64) as fe:
         torch.cuda.synchronize()
         free_before, _ = torch.cuda.mem_get_info()
         fe.match_shard_keys_static(dq.data_ptr(), nq, dt.data_ptr(), nt, 0, keys.data_ptr())
         fe.match_shard_keys_static(dq.data_ptr(), 333, dt.data_ptr(), 70_001, 9, keys_small.data_ptr())
+        fe.match_shard_keys_static(wide_q.data_ptr(), nq_wide, dt.data_ptr(), nt_wide, 0, keys_wide.data_ptr())
         fe.sync()
         free_after, _ = torch.cuda.mem_get_info()
         assert free_after == free_before, (free_before, free_after)
         got, got_small = keys.cpu().numpy(), keys_small.cpu().numpy()[:333]
         assert np.array_equal(got, _keys(fe, fe.match_shard_keys, dq, nq, dt, nt, 0))
         assert np.array_equal(got_small, _keys(fe, fe.match_shard_keys, dq, 333, dt, 70_001, 9))
+        fe.match_shard_keys(wide_q.data_ptr(), nq_wide, dt.data_ptr(), nt_wide, 0, keys_wide_want.data_ptr())
+        fe.sync()
+        assert torch.equal(keys_wide, keys_wide_want)
+        assert int((keys_wide[:, 0] >> 32).max()) <= 256 and int((keys_wide[:, 1] & 0xffffffff).max()) < nt_wide
 
 
 def test_static_scratch_against_the_cpu_checker():
