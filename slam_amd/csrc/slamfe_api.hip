@@ -101,7 +101,7 @@ struct slamfe_ctx {
     int fm_qpt = 1, fm_chunk = 64, fm_nchunks = 1; // plan for frame-vs-frame matching
     Scratch match_part, match_q, match_t, match_o;
     uint8_t* map_desc = nullptr;
-    Scratch pj_in, pj_cand, pj_candn, pj_matched, pj_cells, pj_sorted, pj_cnt, pj_rank;
+    Scratch pj_in, pj_cand, pj_candn, pj_cells, pj_sorted, pj_cnt, pj_rank;
     // The grid over the device-resident visible set (pj_cells, pj_sorted) is built by
     // slamfe_reproject for the radius of the most recent search (the reference's
     // constant before any search, Init.cc:242) and reused by the search if the
@@ -704,7 +704,7 @@ void slamfe_destroy(slamfe_ctx* c)
     void* bufs[] = {c->pyr, c->blur, c->in_stage, c->taps, c->cand, c->cand_cnt, c->band_hist,
                     c->band_off, c->level_kept, c->level_cutoff, c->kp_key, c->kp_level,
                     c->kp_count, c->kps, c->desc, c->kp_mom, c->kp_rot, c->match_out, c->map_desc, c->match_part.p,
-                    c->match_q.p, c->match_t.p, c->match_o.p, c->pj_in.p, c->pj_cand.p, c->pj_candn.p, c->pj_matched.p, c->pj_cells.p,
+                    c->match_q.p, c->match_t.p, c->match_o.p, c->pj_in.p, c->pj_cand.p, c->pj_candn.p, c->pj_cells.p,
                     c->pj_sorted.p, c->pj_cnt.p, c->pj_rank.p, c->ing_taps.p,
                     c->ing_bgr.p, c->map_xyz, c->rp_uv_all.p, c->rp_mask.p, c->rp_off.p, c->rp_total.p,
                     c->vis_uv.p, c->vis_idx.p, c->tri_in.p, c->tri_out.p};
@@ -1332,7 +1332,6 @@ int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n
     if ((rc = grow(c, c->pj_in, in_bytes))) return rc;
     if ((rc = grow(c, c->pj_cand, (size_t)n_inl * SLAMFE_PROJ_K * 4))) return rc;
     if ((rc = grow(c, c->pj_candn, (size_t)n_inl * 4))) return rc;
-    if ((rc = grow(c, c->pj_matched, (size_t)n_inl * 4))) return rc;
     // the grid over the visible set: already built by slamfe_reproject for this radius?
     const bool have_grid = from_visible_set && c->pj_grid_ready && radius == c->pj_grid_radius;
     if (!have_grid && (rc = grow_projection_grid(c, R))) return rc;
@@ -1347,8 +1346,14 @@ int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n
         d_uv = (const float*)((const uint8_t*)c->pj_in.p + o_uv);
         d_ids = (const int32_t*)((const uint8_t*)c->pj_in.p + o_ids);
     }
-    HIPCHK(c, hipMemcpyAsync(c->pj_in.p, c->h_pin, in_bytes, hipMemcpyHostToDevice, s));
-    const int32_t* d_idx = (const int32_t*)c->pj_in.p;
+    // Host-supplied visible set: everything goes up in one transfer.  Device-resident
+    // set: the kernels read the inlier indices (a few KB) from the page-locked buffer
+    // itself -- one transfer command less on a call that is a chain of short steps.
+    const int32_t* d_idx = (const int32_t*)(c->h_pin + o_idx);
+    if (!from_visible_set) {
+        HIPCHK(c, hipMemcpyAsync(c->pj_in.p, c->h_pin, in_bytes, hipMemcpyHostToDevice, s));
+        d_idx = (const int32_t*)c->pj_in.p;
+    }
     if (!have_grid) {
         KCHK(c, slamfe_launch_projection_grid(s, d_uv, d_ids, R, nullptr, radius, c->p.max_width, c->p.max_height,
                                               (uint32_t*)c->pj_cells.p, c->pj_sorted.p,
@@ -1363,9 +1368,10 @@ int search_projected(slamfe_ctx* c, uint64_t frame, const int32_t* kp_idx, int n
                                      d_idx, n_inl, d_ids, R, c->map_desc,
                                      radius, max_hamming, c->p.max_width, c->p.max_height,
                                      (const uint32_t*)c->pj_cells.p, c->pj_sorted.p, (uint32_t*)c->pj_cand.p,
-                                     (int32_t*)c->pj_candn.p, (int32_t*)c->pj_matched.p));
-    HIPCHK(c, hipMemcpyAsync(c->h_pin + o_out, c->pj_matched.p, (size_t)n_inl * 4,
-                             hipMemcpyDeviceToHost, s));
+                                     (int32_t*)c->pj_candn.p,
+                                     // the resolve kernel writes the answers to the page-locked
+                                     // buffer itself: no transfer command after it
+                                     (int32_t*)(c->h_pin + o_out)));
     HIPCHK(c, hipStreamSynchronize(s));
     memcpy(matched_point_id, c->h_pin + o_out, (size_t)n_inl * 4);
     return SLAMFE_OK;
