@@ -701,35 +701,103 @@ __device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p, uint32_t v)
     return old;
 }
 
-__device__ __forceinline__ int fast_score_lds(const uint8_t* c, int thr)
+// Appends the survivors of one pretest task to a list of 16-bit entries in LDS.
+// f0 / f1: bit 7 of byte j set iff pixel j / pixel 4 + j of the task survives (the
+// other bits clear); slot: where the lane's first entry goes; e2: the entry of
+// pixel 0 in both halves.  Per pixel: one byte-select compare into a scalar register
+// pair, one 16-bit store of either register half, one add in place -- the compiler's
+// form of the same loop (test, compare, add into a copy, move back, add for the
+// entry) costs twice the vector instructions, in the pass that has the most.
+// The lane mask is restored before the block ends, and the stores have landed.
+__device__ __forceinline__ void lds_append_survivors(uint32_t f0, uint32_t f1, uint16_t* slot, uint32_t e2)
 {
-    // ring pixel offsets in the LDS tile (pitch FL_W)
+    uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)slot;
+    // (halves added separately: the first task of a row starts three entries before the row)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    union pk { uint32_t u; us2 v; };
+    auto plus = [&](unsigned short k) { pk a, r; a.u = e2; r.v = a.v + us2{k, (unsigned short)(k + 1)}; return r.u; };
+    const uint32_t e01 = plus(0), e23 = plus(2), e45 = plus(4), e67 = plus(6);
+    const uint32_t zero = 0;
+    uint64_t saved, k0, k1, k2, k3, k4, k5, k6, k7;
+    // (all eight compares run under the full lane mask, before any store narrows it)
+#define CMP(k, f, byte) "v_cmp_ne_u32_sdwa %[" k "], %[" f "], %[z] src0_sel:BYTE_" byte " src1_sel:DWORD\n\t"
+#define APPEND(k, st, e) "s_mov_b64 exec, %[" k "]\n\t" st " %[a], %[" e "]\n\tv_add_u32_e32 %[a], 2, %[a]\n\t"
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 CMP("k0", "f0", "0") CMP("k1", "f0", "1") CMP("k2", "f0", "2") CMP("k3", "f0", "3")
+                 CMP("k4", "f1", "0") CMP("k5", "f1", "1") CMP("k6", "f1", "2") CMP("k7", "f1", "3")
+                 APPEND("k0", "ds_write_b16", "e01") APPEND("k1", "ds_write_b16_d16_hi", "e01")
+                 APPEND("k2", "ds_write_b16", "e23") APPEND("k3", "ds_write_b16_d16_hi", "e23")
+                 APPEND("k4", "ds_write_b16", "e45") APPEND("k5", "ds_write_b16_d16_hi", "e45")
+                 APPEND("k6", "ds_write_b16", "e67") APPEND("k7", "ds_write_b16_d16_hi", "e67")
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [sv] "=&s"(saved), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3), [k4] "=&s"(k4),
+                   [k5] "=&s"(k5), [k6] "=&s"(k6), [k7] "=&s"(k7), [a] "+v"(addr)
+                 : [f0] "v"(f0), [f1] "v"(f1), [z] "v"(zero), [e01] "v"(e01), [e23] "v"(e23), [e45] "v"(e45),
+                   [e67] "v"(e67)
+                 : "memory");
+#undef APPEND
+#undef CMP
+}
+
+// FAST-9 score of two pixels of the LDS tile at once, one in each 16-bit half of
+// a register.  With r[0..15] the ring and d = v - r, the score is the largest
+// margin m - 1 such that some arc of 9 contiguous ring pixels has all d > m - 1
+// or all d < -(m - 1): m = max(v - min_s max(arc_s), max_s min(arc_s) - v) over
+// the sixteen arcs, each arc three runs of three ring pixels.
+// gfx950 has packed three-input minimum / maximum for 16-bit floats
+// (v_pk_minimum3_f16, v_pk_maximum3_f16), and a pixel value 0 .. 255 taken as the bit
+// pattern of a 16-bit float is a subnormal number (value * 2^-24; the kernel's float
+// mode keeps 16-bit subnormals): minimum and maximum of such numbers are minimum and
+// maximum of the integers, exactly -- no arithmetic is done on them.  The network
+// (three-input minima and maxima of runs of three, then of three runs) therefore
+// costs the same number of instructions for two pixels as it would for one.
+typedef _Float16 fs_h2 __attribute__((ext_vector_type(2)));
+typedef short fs_s2 __attribute__((ext_vector_type(2)));
+union fs_pk {
+    uint32_t u;
+    fs_h2 h;
+    fs_s2 s;
+};
+
+__device__ __forceinline__ void fast_score2_lds(const uint8_t* ca, const uint8_t* cb, int thr, int& sa, int& sb)
+{
     constexpr int R[16][2] = SLAMFE_FAST_RING_INIT;
-    int v = c[0];
-    int r[16];
+    fs_pk r[16], v;
+    v.u = (uint32_t)ca[0] | ((uint32_t)cb[0] << 16);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) r[k] = (int)c[R[k][0] + R[k][1] * FL_W];
-    // min / max of the ring values over every arc of 9 contiguous ring pixels:
-    // arc(s) = r[s..s+8] = three runs of three.  With d = v - r the score terms
-    // are max_s min(d) = v - min_s max(r) and max_s min(-d) = max_s min(r) - v.
-    int mn3[16], mx3[16];
+    for (int k = 0; k < 16; ++k)
+        r[k].u = (uint32_t)ca[R[k][0] + R[k][1] * FL_W] | ((uint32_t)cb[R[k][0] + R[k][1] * FL_W] << 16);
+    fs_pk mn3[16], mx3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        int a = r[k], b = r[(k + 1) & 15], e = r[(k + 2) & 15];
-        mn3[k] = min(a, min(b, e));
-        mx3[k] = max(a, max(b, e));
+        mn3[k].h = __builtin_elementwise_minimum(__builtin_elementwise_minimum(r[k].h, r[(k + 1) & 15].h), r[(k + 2) & 15].h);
+        mx3[k].h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(r[k].h, r[(k + 1) & 15].h), r[(k + 2) & 15].h);
     }
-    int lo = INT_MAX, hi = INT_MIN;
+    fs_pk mn9[16], mx9[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        int mn9 = min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
-        int mx9 = max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
-        lo = min(lo, mx9); // some arc lies entirely at or below lo
-        hi = max(hi, mn9); // some arc lies entirely at or above hi
+        mn9[k].h = __builtin_elementwise_minimum(__builtin_elementwise_minimum(mn3[k].h, mn3[(k + 3) & 15].h), mn3[(k + 6) & 15].h);
+        mx9[k].h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mx3[k].h, mx3[(k + 3) & 15].h), mx3[(k + 6) & 15].h);
     }
-    int m = max(v - lo, hi - v);
+    // lo: some arc lies entirely at or below it; hi: some arc lies entirely at or above it
+    fs_pk lo = mx9[0], hi = mn9[0];
+#pragma unroll
+    for (int k = 1; k < 15; k += 2) {
+        lo.h = __builtin_elementwise_minimum(__builtin_elementwise_minimum(lo.h, mx9[k].h), mx9[k + 1].h);
+        hi.h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(hi.h, mn9[k].h), mn9[k + 1].h);
+    }
+    lo.h = __builtin_elementwise_minimum(lo.h, mx9[15].h);
+    hi.h = __builtin_elementwise_maximum(hi.h, mn9[15].h);
+    // back to integers: margin m = max(v - lo, hi - v) per half
+    fs_pk d1, d2, m;
+    d1.s = v.s - lo.s;
+    d2.s = hi.s - v.s;
+    m.s = __builtin_elementwise_max(d1.s, d2.s);
+    const int ma = (int)m.s[0], mb = (int)m.s[1]; // signed: -255 .. 255
     // corner <=> some arc has all |d| > thr on one side; score = that margin - 1
-    return m > thr ? m - 1 : 0;
+    sa = ma > thr ? ma - 1 : 0;
+    sb = mb > thr ? mb - 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint8_t* __restrict__ pyr,
@@ -816,35 +884,39 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         const bool interior = x0 - 1 >= blo && x0 + TW <= L.w - blo - 1 && y0 - 1 >= blo &&
                               y0 + nrows <= L.h - blo - 1;
         const v2s t2 = {(short)thr, (short)thr};
-        // survivors among the 4 pixels of dword C (ring pixels: U above, D below,
-        // L3 / R3 three to the left / right): bit 7 of byte j of the result is
-        // set iff pixel j survives (the other bits are undefined)
-        auto pretest4 = [&](uint32_t C, uint32_t U, uint32_t D, uint32_t L3, uint32_t R3) -> uint32_t {
-            uint32_t neg[2];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                pk v, p0, p8, p4, p12;
-                if (half == 0) {
-                    v.u = C & 0x00ff00ffu; p0.u = D & 0x00ff00ffu; p8.u = U & 0x00ff00ffu;
-                    p4.u = R3 & 0x00ff00ffu; p12.u = L3 & 0x00ff00ffu;
-                } else { // bytes 1 and 3, widened by one v_perm each
-                    v.u = __builtin_amdgcn_perm(0u, C, 0x0c030c01u);
-                    p0.u = __builtin_amdgcn_perm(0u, D, 0x0c030c01u);
-                    p8.u = __builtin_amdgcn_perm(0u, U, 0x0c030c01u);
-                    p4.u = __builtin_amdgcn_perm(0u, R3, 0x0c030c01u);
-                    p12.u = __builtin_amdgcn_perm(0u, L3, 0x0c030c01u);
-                }
-                v2s hi = __builtin_elementwise_min(__builtin_elementwise_max(p0.v, p8.v),
-                                                   __builtin_elementwise_max(p4.v, p12.v));
-                v2s lo = __builtin_elementwise_max(__builtin_elementwise_min(p0.v, p8.v),
-                                                   __builtin_elementwise_min(p4.v, p12.v));
-                pk r1, r2;
-                r1.v = (v.v + t2) - hi; // < 0  <=>  hi > v + t
-                r2.v = lo - (v.v - t2); // < 0  <=>  lo < v - t
-                neg[half] = r1.u | r2.u; // sign bits: element 0 -> pixel `half`, element 1 -> pixel 2 + half
-            }
+        // A dword's four pixels widened to 16-bit pairs: e = pixels 0 and 2, o = pixels 1 and 3
+        struct wide { pk e, o; };
+        auto widen = [&](uint32_t x) -> wide {
+            wide r;
+            r.e.u = x & 0x00ff00ffu;
+            r.o.u = __builtin_amdgcn_perm(0u, x, 0x0c030c01u);
+            return r;
+        };
+        // sign bits of the result: set iff the pixel survives (v the pixels, p0 / p8
+        // below / above, p4 / p12 three to the right / left)
+        auto pretest2 = [&](pk v, pk p0, pk p8, pk p4, pk p12) -> uint32_t {
+            v2s hi = __builtin_elementwise_min(__builtin_elementwise_max(p0.v, p8.v),
+                                               __builtin_elementwise_max(p4.v, p12.v));
+            v2s lo = __builtin_elementwise_max(__builtin_elementwise_min(p0.v, p8.v),
+                                               __builtin_elementwise_min(p4.v, p12.v));
+            pk r;
+            r.v = t2 - __builtin_elementwise_max(hi - v.v, v.v - lo); // < 0 <=> hi > v + t or lo < v - t
+            return r.u;
+        };
+        // survivors among the 4 pixels of a dword (C widened, U above, D below, P / N
+        // the dwords before / after C in the row, widened): bit 7 of byte j of the
+        // result is set iff pixel j survives (the other bits are undefined).  The
+        // pixels three to the left are P's pixels 1, 3 for C's pixels 0, 2 and
+        // (P's pixel 2, C's pixel 0) for pixels 1, 3; three to the right likewise.
+        auto pretest4 = [&](const wide& C, uint32_t U, uint32_t D, const wide& P, const wide& N) -> uint32_t {
+            const wide u = widen(U), d = widen(D);
+            pk l3o, r3e;
+            l3o.u = __builtin_amdgcn_alignbyte(C.e.u, P.e.u, 2);
+            r3e.u = __builtin_amdgcn_alignbyte(N.o.u, C.o.u, 2);
+            const uint32_t n0 = pretest2(C.e, d.e, u.e, r3e, P.o);
+            const uint32_t n1 = pretest2(C.o, d.o, u.o, N.e, l3o);
             // the high bytes of the four 16-bit results, in pixel order
-            return __builtin_amdgcn_perm(neg[1], neg[0], 0x07030501u);
+            return __builtin_amdgcn_perm(n1, n0, 0x07030501u);
         };
         // (the tasks past the first 256 go to the last wave, which takes no part
         // in the blur below)
@@ -856,34 +928,34 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             uint32_t C0 = row[0], C1 = row[1], Cp = row[-1], Cn = row[2];
             uint32_t U0 = row[-3 * FL_WD], U1 = row[-3 * FL_WD + 1];
             uint32_t D0 = row[3 * FL_WD], D1 = row[3 * FL_WD + 1];
-            // flag of pixel k of the task: bit 7 + 8k for k < 4, bit 6 + 8(k-4) for k >= 4
-#define PRE_BIT(k) ((k) < 4 ? 7 + 8 * (k) : 6 + 8 * ((k) - 4))
-            uint32_t flags = (pretest4(C0, U0, D0, __builtin_amdgcn_alignbyte(C0, Cp, 1),
-                                       __builtin_amdgcn_alignbyte(C1, C0, 3)) & 0x80808080u) |
-                             ((pretest4(C1, U1, D1, __builtin_amdgcn_alignbyte(C1, C0, 1),
-                                        __builtin_amdgcn_alignbyte(Cn, C1, 3)) & 0x80808080u) >> 1);
+            // flags of pixels 0 .. 3 (f0) and 4 .. 7 (f1) of the task: bit 7 of byte j
+            const wide wp = widen(Cp), w0 = widen(C0), w1 = widen(C1), wn = widen(Cn);
+            uint32_t f0 = pretest4(w0, U0, D0, wp, w1);
+            uint32_t f1 = pretest4(w1, U1, D1, w0, wn);
             // pixel k is a score position iff lx = 8m+k in [3, 68] and the image
             // position is inside the band that can still yield a keypoint:
             // keypoints outside [edge, w-edge) x [edge, h-edge) are discarded by
             // the ORB border filter, and NMS looks one pixel further, so scores
             // are needed on [lo, w-lo) x [lo, h-lo) with lo = max(3, edge-1)
             // (tiles whose score area lies inside that band need the column rule only)
-            uint32_t valid;
+            uint32_t v0, v1;
             if (interior) { // uniform: pixels 3..7 of the first task, 0..4 of the last
-                valid = m == 0 ? 0xc0404040u : (m == FB_COLD / 2 - 1 ? 0x808080c0u : 0xc0c0c0c0u);
+                v0 = m == 0 ? 0x80000000u : 0x80808080u;
+                v1 = m == FB_COLD / 2 - 1 ? 0x00000080u : 0x80808080u;
             } else {
                 int gy = y0 - 1 + sy, gxb = x0 - 4 + 8 * m;
                 int kmin = max(3 - 8 * m, blo - gxb), kmax = min(FS_W + 2 - 8 * m, L.w - blo - 1 - gxb);
                 kmin = max(kmin, 0);
                 kmax = min(kmax, 7);
-                valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
-                            ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
+                const uint32_t valid = (gy >= blo && gy < L.h - blo && kmax >= kmin)
+                                           ? ((2u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
                 // bit j of a nibble -> bit 7 + 8j (the four shifted copies of the
                 // nibble inside the product do not overlap)
-                valid = (((valid & 15u) * 0x10204080u) & 0x80808080u) |
-                        ((((valid >> 4) * 0x10204080u) & 0x80808080u) >> 1);
+                v0 = ((valid & 15u) * 0x10204080u) & 0x80808080u;
+                v1 = ((valid >> 4) * 0x10204080u) & 0x80808080u;
             }
-            flags &= valid;
+            f0 &= v0;
+            f1 &= v1;
             // compaction: every lane with survivors reserves its entries with one
             // LDS atomic, issued as the instruction itself (see lds_fetch_add; the
             // compiler's rewrite of atomicAdd with per-lane operands is a serial
@@ -893,19 +965,11 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
             // (same time, twice the code), and one ballot per pixel with
             // rank-addressed stores (fewer vector instructions, eight exec-mask
             // sections, 6 % slower).
-            const uint32_t c = (uint32_t)__popc(flags);
+            const uint32_t c = (uint32_t)(__popc(f0) + __popc(f1));
             if (c) {
-                uint32_t base = lds_fetch_add(&npos, c);
-                int sbase = sy * FS_W + 8 * m - 3;
-                uint8_t* slot = reinterpret_cast<uint8_t*>(pos) + 2u * base;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (flags & (1u << PRE_BIT(k))) {
-                        *reinterpret_cast<uint16_t*>(slot) = (uint16_t)(sbase + k);
-                        slot += 2;
-                    }
+                const uint32_t base = lds_fetch_add(&npos, c);
+                lds_append_survivors(f0, f1, pos + base, ((uint32_t)(sy * FS_W + 8 * m - 3) & 0xffffu) * 0x00010001u);
             }
-#undef PRE_BIT
         }
     }
 
@@ -917,12 +981,17 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                   blur + (size_t)f * g.frame_bytes + L.off);
     __syncthreads();
 
-    // ---- FAST pass C: full score of the pretest survivors
+    // ---- FAST pass C: full score of the pretest survivors, two per lane (survivor k
+    // with survivor k + half; with an odd count the last lane scores one of them twice)
     const uint32_t np = npos;
-    for (uint32_t k = tid; k < np; k += 256) {
-        int i = pos[k];
-        int sy = i / FS_W, sx = i - sy * FS_W;
-        sc[i] = (uint8_t)fast_score_lds(&tile[(sy + 3) * FL_W + FL_X0 + sx + 3], thr);
+    const uint32_t half = (np + 1) >> 1;
+    for (uint32_t k = tid; k < half; k += 256) {
+        const int ia = pos[k], ib = pos[min(k + half, np - 1)];
+        const int ya = ia / FS_W, xa = ia - ya * FS_W, yb = ib / FS_W, xb = ib - yb * FS_W;
+        int sa, sb;
+        fast_score2_lds(&tile[(ya + 3) * FL_W + FL_X0 + xa + 3], &tile[(yb + 3) * FL_W + FL_X0 + xb + 3], thr, sa, sb);
+        sc[ia] = (uint8_t)sa;
+        sc[ib] = (uint8_t)sb;
     }
 
     __syncthreads();
