@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
                                                    uint32_t* __restrict__ cand_cnt, slamfe_level0 l0)
 {
     __shared__ uint32_t tile32[FL_H * FL_WD];
-    __shared__ uint32_t sc32[(FS_N + 3) / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t sc32[(FS_N + 15) / 16 * 4]; // cleared 16 bytes at a time
     __shared__ uint16_t pos[FS_N];
     __shared__ uint32_t list[SLAMFE_FB_TILES * SLAMFE_TILE_CAND];
     __shared__ uint32_t nlist[SLAMFE_FB_TILES], npos;
@@ -842,7 +842,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
         if (pc == 5) v.w = (v.w & 0x00ffffffu) | 0x82000000u;
         *reinterpret_cast<uint4*>(&tile32[ly * FL_WD + 4 * pc]) = v;
     }
-    for (int i = tid; i < ((nrows + 2) * FS_W + 3) / 4; i += 256) sc32[i] = 0;
+    for (int i = tid; i < ((nrows + 2) * FS_W + 15) / 16; i += 256)
+        reinterpret_cast<uint4*>(sc32)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     // REFLECT_101 at the left / right image border (the blur reads 3 px across
     // it): copy the mirrored bytes inside LDS.  Only border tiles take this.
@@ -997,6 +998,8 @@ __global__ __launch_bounds__(256) void k_fast_blur(slamfe_dev_geom g, const uint
     __syncthreads();
 
     // ---- FAST pass D: NMS of the survivors, border filter, emission
+    // (A list of the survivors that have a score, appended to by the pass above so
+    // that this pass runs on full waves, cost as much as it saved.)
     for (uint32_t k = tid; k < np; k += 256) {
         int i = pos[k];
         int s = sc[i];
