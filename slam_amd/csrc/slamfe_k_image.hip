@@ -133,8 +133,11 @@ __device__ __forceinline__ slamfe_us2 as_us2(uint32_t x)
 // source row (4 values of 8.8 fixed point, two dwords) is computed once and used
 // by both destination rows that blend it (consecutive destination rows share a
 // source row: 1.2 source rows per destination row instead of 2).
-#define RS_ROWS 4
-#define RS_PRE 7 /* source rows requested at once */
+// (8 rows per wave: with 4 the pyramid of 1024 VGA frames took 9 % longer -- a wave's
+// life is one round of loads, and per-wave set-up (taps, selectors) is amortised over
+// twice the rows; with 12 or 16 the source rows held in registers cost occupancy.)
+#define RS_ROWS 8
+#define RS_PRE 11 /* source rows requested at once */
 
 __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nframes,
                                                 uint8_t* __restrict__ pyr,
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void k_resize(slamfe_dev_geom g, int l, int nf
         const int sy_last = (int)(ty_last & 0xffffu) + ((ty_last >> 16) ? 1 : 0); // uniform
         uint2 Hprev = make_uint2(0, 0), Hcur = make_uint2(0, 0);
         if (sy_last - sy < RS_PRE) {
-            // (the usual case: RS_ROWS rows at scale 1.2 blend at most six source rows)
+            // (the usual case: RS_ROWS rows at scale 1.2 blend at most eleven source rows)
             // all source rows are requested at once, so that the wave waits for memory
             // once and not once per row
             uint3 R[RS_PRE];
