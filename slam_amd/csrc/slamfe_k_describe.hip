@@ -277,18 +277,22 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
     static_assert(DP_PITCH == 64, "the sample address below shifts y by 6");
     const uint32_t c0 = (uint32_t)(uintptr_t)(lds_bytes)c - 0x4B400000u * 65u;
     unsigned long long word[4];
+    // all eight sample reads are issued before the first comparison: one LDS latency
+    // per keypoint, not four
+    int v[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             desc_v2f pt = D.P[j][e] * AB + D.Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
             pt = pt + magic;
             const uint32_t at = (__float_as_uint(pt.y) << 6) + __float_as_uint(pt.x) + c0;
-            v[e] = *(lds_bytes)(uintptr_t)at;
+            v[j][e] = *(lds_bytes)(uintptr_t)at;
         }
-        word[j] = __ballot(v[0] < v[1]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) word[j] = __ballot(v[j][0] < v[j][1]);
     if (lane < 4) {
         unsigned long long o = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
         reinterpret_cast<unsigned long long*>(out32)[lane] = o;
