@@ -136,6 +136,31 @@ def test_extract_reference_mode(fe_ref):
         assert np.all(np.diff(key) > 0)  # FAST's row-major order
 
 
+@pytest.mark.parametrize("thr", [1, 20, 127, 254])
+def test_fast_scores_at_extreme_contrast(thr):
+    # The score network runs on pixel values taken as 16-bit float bit patterns, two
+    # survivors per lane: isolated 0 / 255 dots and small blobs on grounds of 0, 1, 127,
+    # 254 and 255 give margins from 1 to 255 (scores 0 .. 254), ties between neighbours
+    # in the non-maximum suppression, and survivor counts of either parity in a tile
+    # group.  FAST-only mode returns the raw responses in row-major order.
+    from slam_amd.frontend import FrontEnd
+    w, h = 397, 283
+    rng = np.random.default_rng(100 + thr)
+    img = np.zeros((h, w), np.uint8)
+    for x0, ground in ((0, 0), (80, 1), (160, 127), (240, 254), (320, 255)):
+        img[:, x0:x0 + 80] = ground
+    for _ in range(900):  # dots
+        img[rng.integers(0, h), rng.integers(0, w)] = rng.choice([0, 1, 126, 128, 254, 255])
+    for _ in range(120):  # blobs of 2 x 2 .. 4 x 4 with one value
+        y, x, n = rng.integers(0, h - 4), rng.integers(0, w - 4), rng.integers(2, 5)
+        img[y:y + n, x:x + n] = rng.choice([0, 255, 64, 192])
+    with FrontEnd(mode=abi.MODE_PROVIDED, fast_threshold=thr, max_width=w, max_height=h) as fe:
+        f = fe.extract_keypoints(img)
+        kps, desc = O.extract(oracle_params(fe), img)
+        assert_frame_equal(f, kps, desc)
+        assert len(kps) > 20 and kps["response"].max() == 254
+
+
 def test_extract_bgr_input(fe_orb, fe_ref):
     g = synth.textured_canvas(320, 240, 48)
     bgr = np.stack([np.roll(g, 1, 0), g, np.roll(g, 2, 1)], axis=2)
