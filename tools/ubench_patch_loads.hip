@@ -9,6 +9,7 @@
 //              aligned pieces that cover the lane's 16 bytes)
 //   variant 4: the image in tiles of 16 x 8 pixels (one 128-byte line each): the
 //              3 x 5 tiles that hold the patch, two 16-byte pieces per lane
+//   variant 5: variant 2 (aligned) with non-temporal loads
 // Build: hipcc --offload-arch=gfx950 -O3 -o ubench_patch_loads ubench_patch_loads.hip
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,6 +50,12 @@ __global__ __launch_bounds__(256) void k_fetch(const uint8_t* __restrict__ img, 
             if (lane < 56)
                 b = *reinterpret_cast<const uint4*>(frame + ((size_t)(ty0 + t1 / 3) * tpr + tx0 + t1 % 3) * 128 + rw * 16);
             a.x ^= b.y; a.y ^= b.z; a.z ^= b.w; a.w ^= b.x;
+        } else if (VARIANT == 5) {
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            if (lane < 62) {
+                const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>((uintptr_t)p & ~(uintptr_t)15));
+                a = make_uint4(t.x, t.y, t.z, t.w);
+            }
         } else if (VARIANT < 3) {
             if (lane < 62) __builtin_memcpy(&a, p, 16);
         } else {
@@ -82,7 +89,7 @@ int main()
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
-    for (int v = 0; v < 5; ++v) {
+    for (int v = 0; v < 6; ++v) {
         float best = 1e30f;
         for (int rep = 0; rep < 6; ++rep) {
             CHK(hipEventRecord(e0, 0));
@@ -92,6 +99,7 @@ int main()
             if (v == 2) hipLaunchKernelGGL(k_fetch<2>, grid, dim3(256), 0, 0, img, out);
             if (v == 3) hipLaunchKernelGGL(k_fetch<3>, grid, dim3(256), 0, 0, img, out);
             if (v == 4) hipLaunchKernelGGL(k_fetch<4>, grid, dim3(256), 0, 0, img, out);
+            if (v == 5) hipLaunchKernelGGL(k_fetch<5>, grid, dim3(256), 0, 0, img, out);
             CHK(hipEventRecord(e1, 0));
             CHK(hipEventSynchronize(e1));
             float ms;
