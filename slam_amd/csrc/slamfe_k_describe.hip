@@ -196,7 +196,13 @@ __global__ __launch_bounds__(256) void k_finish(slamfe_dev_geom g, int slot_base
 // of 48 bytes at an arbitrary offset -- against 18 here.)
 #define DP_TCOLS 4
 #define DP_TROWS 6
-#define DP_PITCH (16 * DP_TCOLS)           /* bytes of a patch row in LDS */
+/* Bytes of a patch row in LDS: one 16-byte piece more than the four tile columns.  With
+ * 64 bytes a row is 16 of the 64 banks, rows y and y + 4 share their banks, the eight
+ * rows of a tile are staged two to a bank and the samples of a keypoint fall on 40 of
+ * the 64 banks; with 80 the rows start at banks 0, 20, 40, 60, 16, ...: every bank in
+ * use, and the eight 16-byte pieces of a tile on eight different bank quadruples. */
+#define DP_PITCH 80
+#define DP_PITCH_U4 (DP_PITCH / 16)
 #define DP_LDS_ROWS (8 * DP_TROWS)
 #define DP_PIECES (DP_TCOLS * DP_TROWS * 8) /* 16-byte pieces of the largest tile region */
 
@@ -266,7 +272,7 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
 {
 #pragma unroll
     for (int it = 0; it < DP_NIT; ++it)
-        if (D.tcol[it] < R.ncols && D.trow[it] < R.nrows) my[(D.trow[it] * 8 + D.trw[it]) * DP_TCOLS + D.tcol[it]] = r[it];
+        if (D.tcol[it] < R.ncols && D.trow[it] < R.nrows) my[(D.trow[it] * 8 + D.trw[it]) * DP_PITCH_U4 + D.tcol[it]] = r[it];
     // only this wavefront reads what it wrote: LDS operations of one wave are
     // ordered, the fences keep the compiler from moving accesses across
     wave_lds_fence();
@@ -275,11 +281,11 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
     const desc_v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
     // Adding 1.5 * 2^23 rounds to the nearest integer r (ties to even, as cvRound)
     // and leaves the float's bit pattern at 0x4B400000 + r.  The sample's LDS address
-    // c + 64 * ry + rx is therefore (bits(y) << 6) + bits(x) plus a constant, in
-    // 32-bit modular arithmetic: one v_lshl_add and one v_add per sample.
+    // c + 80 * ry + rx is therefore (bits(y) << 6) + (bits(y) << 4) + bits(x) plus a
+    // constant, in 32-bit modular arithmetic: two v_lshl_add and one v_add per sample.
     const desc_v2f magic = {12582912.f, 12582912.f};
-    static_assert(DP_PITCH == 64, "the sample address below shifts y by 6");
-    const uint32_t c0 = (uint32_t)(uintptr_t)(lds_bytes)c - 0x4B400000u * 65u;
+    static_assert(DP_PITCH == 64 + 16, "the sample address below is (y << 6) + (y << 4) + x");
+    const uint32_t c0 = (uint32_t)(uintptr_t)(lds_bytes)c - 0x4B400000u * (uint32_t)(DP_PITCH + 1);
     unsigned long long word[4];
     // all eight sample reads are issued before the first comparison: one LDS latency
     // per keypoint, not four
@@ -290,7 +296,8 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
         for (int e = 0; e < 2; ++e) {
             desc_v2f pt = D.P[j][e] * AB + D.Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
             pt = pt + magic;
-            const uint32_t at = (__float_as_uint(pt.y) << 6) + __float_as_uint(pt.x) + c0;
+            const uint32_t by = __float_as_uint(pt.y);
+            const uint32_t at = (by << 6) + ((by << 4) + __float_as_uint(pt.x)) + c0;
             v[j][e] = *(lds_bytes)(uintptr_t)at;
         }
     }
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256) void k_describe(slamfe_dev_geom g, const uint8
                                                   const float2* __restrict__ kp_rot,
                                                   uint8_t* __restrict__ desc, int max_kp, int nframes)
 {
-    __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_TCOLS];
+    __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_PITCH_U4];
     const int f = wg_frame();
     if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(slamfe_dev_geom g, cons
                                                          int max_kp, int mode, int patch_size, int nframes,
                                                          slamfe_host_rows host, slamfe_level0 l0)
 {
-    __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_TCOLS];
+    __shared__ uint4 patch128[4][DP_LDS_ROWS * DP_PITCH_U4];
     const int f = wg_frame();
     if (f >= nframes) return;
     const int slot = (slot_base + f) % nslots;
