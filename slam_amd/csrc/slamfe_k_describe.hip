@@ -259,8 +259,9 @@ __device__ __forceinline__ void describe_load(const describe_lane& D, const uint
     for (int it = 0; it < DP_NIT; ++it) {
         r[it] = make_uint4(0, 0, 0, 0);
         if (D.tcol[it] < R.ncols && D.trow[it] < R.nrows)
-            r[it] = *reinterpret_cast<const uint4*>(level + ((size_t)(R.ty0 + D.trow[it]) * tpr + R.tx0 + D.tcol[it]) * 128 +
-                                                    D.trw[it] * 16);
+            // (a level is far below 4 GiB: 32-bit offsets from the level's uniform base)
+            r[it] = *reinterpret_cast<const uint4*>(
+                level + (uint32_t)(((R.ty0 + D.trow[it]) * tpr + R.tx0 + D.tcol[it]) * 128 + D.trw[it] * 16));
     }
 }
 
