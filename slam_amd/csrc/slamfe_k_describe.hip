@@ -282,11 +282,11 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
     const desc_v2f AB = {rot.x, rot.y}, NBA = {-rot.y, rot.x};
     // Adding 1.5 * 2^23 rounds to the nearest integer r (ties to even, as cvRound)
     // and leaves the float's bit pattern at 0x4B400000 + r.  The sample's LDS address
-    // c + 80 * ry + rx is therefore (bits(y) << 6) + (bits(y) << 4) + bits(x) plus a
-    // constant, in 32-bit modular arithmetic: two v_lshl_add and one v_add per sample.
+    // c + 80 * ry + rx is therefore 80 * (low 24 bits of bits(y)) + bits(x) plus a
+    // constant, in 32-bit modular arithmetic: one v_mad_u32_u24 and one v_add per sample
+    // (the low 24 bits are 0x400000 + ry, positive).
     const desc_v2f magic = {12582912.f, 12582912.f};
-    static_assert(DP_PITCH == 64 + 16, "the sample address below is (y << 6) + (y << 4) + x");
-    const uint32_t c0 = (uint32_t)(uintptr_t)(lds_bytes)c - 0x4B400000u * (uint32_t)(DP_PITCH + 1);
+    const uint32_t c0 = (uint32_t)(uintptr_t)(lds_bytes)c - (0x400000u * (uint32_t)DP_PITCH + 0x4B400000u);
     unsigned long long word[4];
     // all eight sample reads are issued before the first comparison: one LDS latency
     // per keypoint, not four
@@ -297,8 +297,7 @@ __device__ __forceinline__ void describe_finish(const describe_lane& D, const ui
         for (int e = 0; e < 2; ++e) {
             desc_v2f pt = D.P[j][e] * AB + D.Q[j][e] * NBA; // (px*a - py*b, px*b + py*a)
             pt = pt + magic;
-            const uint32_t by = __float_as_uint(pt.y);
-            const uint32_t at = (by << 6) + ((by << 4) + __float_as_uint(pt.x)) + c0;
+            const uint32_t at = __umul24(__float_as_uint(pt.y), (uint32_t)DP_PITCH) + __float_as_uint(pt.x) + c0;
             v[j][e] = *(lds_bytes)(uintptr_t)at;
         }
     }
